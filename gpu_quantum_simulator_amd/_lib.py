@@ -1,0 +1,107 @@
+"""ctypes binding of libqsim.so (include/qsim.h).  Loading fails loudly: there is no Python or CPU
+fallback for any entry point — if the HIP extension is missing the package is unusable by design."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_long, c_size_t, c_uint64, c_void_p
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libqsim.so")
+CLI_PATH = os.path.join(PKG_DIR, "bin", "qsim")
+
+QSIM_OK, ERR_ARG, ERR_ALLOC, ERR_DEVICE, ERR_OPEN, ERR_PARSE = range(6)
+GATE_U1, GATE_CX, GATE_U2 = 1, 2, 3
+OPT_FUSE, OPT_PROFILE, OPT_TILE_BITS, OPT_TILE_LOW_BITS, OPT_MAX_PENDING, OPT_TILE_MAX_OPS, OPT_GRID_CAP = range(1, 8)
+K_NAMES = ("init", "gate1", "gate1_lo", "phase", "cx", "gate2", "tile", "pack")
+K_COUNT = len(K_NAMES)
+
+
+class QsimStats(ctypes.Structure):
+    _fields_ = [("gates", c_uint64), ("launches", c_uint64), ("algorithmic_bytes", c_double),
+                ("k_launches", c_uint64 * K_COUNT), ("k_bytes", c_double * K_COUNT), ("k_ms", c_double * K_COUNT)]
+
+    def as_dict(self) -> dict:
+        return {"gates": int(self.gates), "launches": int(self.launches),
+                "algorithmic_bytes": float(self.algorithmic_bytes),
+                "kernels": {K_NAMES[k]: {"launches": int(self.k_launches[k]), "bytes": float(self.k_bytes[k]),
+                                         "ms": float(self.k_ms[k])} for k in range(K_COUNT)}}
+
+
+SCHED_CB = ctypes.CFUNCTYPE(None, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_double), c_int)
+
+# every symbol include/qsim.h declares: name -> (restype, argtypes)
+_DP = POINTER(c_double)
+SIGNATURES = {
+    "qsim_device_count": (c_int, []),
+    "qsim_last_error": (c_char_p, []),
+    "qsim_create": (c_int, [POINTER(c_void_p), c_int, c_int]),
+    "qsim_create_external": (c_int, [POINTER(c_void_p), c_int, c_int, c_void_p]),
+    "qsim_destroy": (None, [c_void_p]),
+    "qsim_reset": (c_int, [c_void_p]),
+    "qsim_num_qubits": (c_int, [c_void_p]),
+    "qsim_set_option": (c_int, [c_void_p, c_int, c_long]),
+    "qsim_get_option": (c_long, [c_void_p, c_int]),
+    "qsim_apply_1q": (c_int, [c_void_p, _DP, c_int]),
+    "qsim_apply_cx": (c_int, [c_void_p, c_int, c_int]),
+    "qsim_apply_2q": (c_int, [c_void_p, _DP, c_int, c_int]),
+    "qsim_flush": (c_int, [c_void_p]),
+    "qsim_sync": (c_int, [c_void_p]),
+    "qsim_read": (c_int, [c_void_p, c_uint64, c_uint64, _DP]),
+    "qsim_write": (c_int, [c_void_p, c_uint64, c_uint64, _DP]),
+    "qsim_norm2": (c_int, [c_void_p, _DP]),
+    "qsim_device_ptr": (c_void_p, [c_void_p]),
+    "qsim_stream": (c_void_p, [c_void_p]),
+    "qsim_get_stats": (c_int, [c_void_p, POINTER(QsimStats)]),
+    "qsim_reset_stats": (c_int, [c_void_p]),
+    "qsim_circuit_parse_file": (c_int, [c_char_p, POINTER(c_void_p)]),
+    "qsim_circuit_parse_text": (c_int, [c_char_p, c_size_t, POINTER(c_void_p)]),
+    "qsim_circuit_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "qsim_circuit_free": (None, [c_void_p]),
+    "qsim_circuit_num_qubits": (c_int, [c_void_p]),
+    "qsim_circuit_num_gates": (c_long, [c_void_p]),
+    "qsim_circuit_append_1q": (c_int, [c_void_p, _DP, c_int]),
+    "qsim_circuit_append_cx": (c_int, [c_void_p, c_int, c_int]),
+    "qsim_circuit_append_2q": (c_int, [c_void_p, _DP, c_int, c_int]),
+    "qsim_circuit_gate": (c_int, [c_void_p, c_long, POINTER(c_int), POINTER(c_int), POINTER(c_int), _DP]),
+    "qsim_circuit_error": (c_char_p, []),
+    "qsim_run_circuit": (c_int, [c_void_p, c_void_p, c_long, c_long]),
+    "qsim_gate_matrix": (c_int, [c_char_p, _DP]),
+    "qsim_plan_circuit": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(QsimStats)]),
+    "qsim_schedule_circuit": (c_int, [c_void_p, c_int, c_int, c_int, c_int, SCHED_CB, c_void_p]),
+}
+# include/qsim_legacy.h
+LEGACY_SYMBOLS = ("compute_state_vector", "execute_single_qubit_gate", "execute_cnot")
+
+_lib = None
+
+
+class QsimError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"qsim error {code}: {message}")
+        self.code = code
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C gpu_quantum_simulator_amd/csrc` "
+                "(or __graft_entry__.build()).  There is no fallback implementation.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here = header and library disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != QSIM_OK:
+        lib = load()
+        msg = lib.qsim_last_error() or b""
+        if rc in (ERR_OPEN, ERR_PARSE) and not msg:
+            msg = lib.qsim_circuit_error() or b""
+        raise QsimError(rc, msg.decode(errors="replace"))

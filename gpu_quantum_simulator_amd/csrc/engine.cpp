@@ -1,0 +1,553 @@
+// engine.cpp — the C ABI of include/qsim.h: device state, gate queue, scheduler driver, launches, stats.
+// Host C++ compiled by hipcc for the HIP runtime API; every kernel lives in kernels.hip.
+//
+// There is no CPU execution path in this file or anywhere in libqsim.so: if the HIP runtime reports no
+// usable device, qsim_create() fails with QSIM_ERR_DEVICE.
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "circuit.h"
+#include "qsim_internal.h"
+#include "scheduler.h"
+
+using namespace qsim;
+
+// ---- errors --------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return fail(e_ == hipErrorOutOfMemory ? QSIM_ERR_ALLOC : QSIM_ERR_DEVICE, "%s failed: %s", #expr, \
+                        hipGetErrorString(e_));                                                             \
+    } while (0)
+
+extern "C" const char *qsim_last_error(void) { return g_err.c_str(); }
+
+extern "C" int qsim_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---- state ---------------------------------------------------------------------------------------------
+struct QueuedGate {
+    int kind, q0, q1;
+    cd m[16];
+};
+
+struct ProfEvent {
+    hipEvent_t start, stop;
+    int kclass;
+};
+
+struct qsim_state {
+    int n = 0, device = 0;
+    hipStream_t stream = nullptr;
+    double2 *amps = nullptr;
+    bool owns = false;
+    // options
+    int fuse = 3, profile = 0, tile_bits = 12, tile_low_bits = 7, tile_max_ops = 24, grid_cap = 0;
+    long max_pending = 1L << 16;
+    // queue
+    std::vector<QueuedGate> queue;
+    // op ring for tile passes
+    TileOp *d_ops = nullptr, *h_ops = nullptr;
+    size_t ops_cap = 0, ops_used = 0;
+    double *d_scalar = nullptr;
+    // stats
+    qsim_stats stats{};
+    std::vector<ProfEvent> events;      // recorded, not yet resolved
+    std::vector<hipEvent_t> event_pool; // reusable
+};
+
+static constexpr size_t kOpsCap = 16384;
+
+static int make_state(qsim_state **out, int num_q, int device, void *ext) {
+    if (!out) return fail(QSIM_ERR_ARG, "qsim_create: out is NULL");
+    *out = nullptr;
+    if (num_q < 0 || num_q > 40) return fail(QSIM_ERR_ARG, "qsim_create: %d qubits unsupported", num_q);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(QSIM_ERR_DEVICE, "no HIP device available (libqsim has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(QSIM_ERR_ARG, "device %d out of range (%d present)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    qsim_state *s = new qsim_state();
+    s->n = num_q;
+    s->device = device;
+    const size_t bytes = (size_t)16 << num_q;
+    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        if (ext) s->amps = (double2 *)ext;
+        else { e = hipMalloc((void **)&s->amps, bytes); s->owns = (e == hipSuccess); }
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_ops, kOpsCap * sizeof(TileOp));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_ops, kOpsCap * sizeof(TileOp), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_scalar, 64);
+    if (e != hipSuccess) {
+        const int code = fail(e == hipErrorOutOfMemory ? QSIM_ERR_ALLOC : QSIM_ERR_DEVICE,
+                              "Malloc error: %s (state needs %zu bytes)", hipGetErrorString(e), bytes);
+        qsim_destroy(s);
+        return code;
+    }
+    s->ops_cap = kOpsCap;
+    *out = s;
+    return qsim_reset(s);
+}
+
+extern "C" int qsim_create(qsim_state **out, int num_q, int device) { return make_state(out, num_q, device, nullptr); }
+extern "C" int qsim_create_external(qsim_state **out, int num_q, int device, void *device_amps) {
+    if (!device_amps) return fail(QSIM_ERR_ARG, "qsim_create_external: device_amps is NULL");
+    return make_state(out, num_q, device, device_amps);
+}
+
+extern "C" void qsim_destroy(qsim_state *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (auto &pe : s->events) { (void)hipEventDestroy(pe.start); (void)hipEventDestroy(pe.stop); }
+    for (auto ev : s->event_pool) (void)hipEventDestroy(ev);
+    if (s->owns && s->amps) (void)hipFree(s->amps);
+    if (s->d_ops) (void)hipFree(s->d_ops);
+    if (s->h_ops) (void)hipHostFree(s->h_ops);
+    if (s->d_scalar) (void)hipFree(s->d_scalar);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+extern "C" int qsim_num_qubits(const qsim_state *s) { return s ? s->n : -1; }
+extern "C" void *qsim_device_ptr(qsim_state *s) { return s ? (void *)s->amps : nullptr; }
+extern "C" void *qsim_stream(qsim_state *s) { return s ? (void *)s->stream : nullptr; }
+
+extern "C" int qsim_set_option(qsim_state *s, int option, long value) {
+    if (!s) return fail(QSIM_ERR_ARG, "NULL state");
+    if (!s->queue.empty()) {
+        const int rc = qsim_flush(s); // options apply to gates queued after the call
+        if (rc) return rc;
+    }
+    switch (option) {
+    case QSIM_OPT_FUSE:
+        if (value < 0 || value > 3) return fail(QSIM_ERR_ARG, "fuse level %ld not in 0..3", value);
+        s->fuse = (int)value;
+        break;
+    case QSIM_OPT_PROFILE: s->profile = value != 0; break;
+    case QSIM_OPT_TILE_BITS:
+        if (value < 8 || value > 13) return fail(QSIM_ERR_ARG, "tile_bits %ld not in 8..13", value);
+        s->tile_bits = (int)value;
+        break;
+    case QSIM_OPT_TILE_LOW_BITS:
+        if (value < 4 || value > 11) return fail(QSIM_ERR_ARG, "tile_low_bits %ld not in 4..11", value);
+        s->tile_low_bits = (int)value;
+        break;
+    case QSIM_OPT_MAX_PENDING:
+        if (value < 1) return fail(QSIM_ERR_ARG, "max_pending must be positive");
+        s->max_pending = value;
+        break;
+    case QSIM_OPT_TILE_MAX_OPS:
+        if (value < 1 || value > 4096) return fail(QSIM_ERR_ARG, "tile_max_ops %ld not in 1..4096", value);
+        s->tile_max_ops = (int)value;
+        break;
+    case QSIM_OPT_GRID_CAP:
+        if (value < 0) return fail(QSIM_ERR_ARG, "grid_cap must be >= 0");
+        s->grid_cap = (int)value;
+        break;
+    default: return fail(QSIM_ERR_ARG, "unknown option %d", option);
+    }
+    return QSIM_OK;
+}
+
+extern "C" long qsim_get_option(const qsim_state *s, int option) {
+    if (!s) return -1;
+    switch (option) {
+    case QSIM_OPT_FUSE: return s->fuse;
+    case QSIM_OPT_PROFILE: return s->profile;
+    case QSIM_OPT_TILE_BITS: return s->tile_bits;
+    case QSIM_OPT_TILE_LOW_BITS: return s->tile_low_bits;
+    case QSIM_OPT_MAX_PENDING: return s->max_pending;
+    case QSIM_OPT_TILE_MAX_OPS: return s->tile_max_ops;
+    case QSIM_OPT_GRID_CAP: return s->grid_cap;
+    default: return -1;
+    }
+}
+
+// ---- profiling events ----------------------------------------------------------------------------------
+static hipEvent_t take_event(qsim_state *s) {
+    if (!s->event_pool.empty()) {
+        hipEvent_t e = s->event_pool.back();
+        s->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+static int resolve_events(qsim_state *s) {
+    if (s->events.empty()) return QSIM_OK;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (auto &pe : s->events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) s->stats.k_ms[pe.kclass] += ms;
+        s->event_pool.push_back(pe.start);
+        s->event_pool.push_back(pe.stop);
+    }
+    s->events.clear();
+    return QSIM_OK;
+}
+
+struct LaunchScope { // records a start/stop pair around one launch when profiling is on
+    qsim_state *s;
+    ProfEvent pe{};
+    bool on;
+    LaunchScope(qsim_state *st, int kclass) : s(st), on(st->profile != 0) {
+        if (on) {
+            pe.kclass = kclass;
+            pe.start = take_event(s);
+            pe.stop = take_event(s);
+            (void)hipEventRecord(pe.start, s->stream);
+        }
+    }
+    ~LaunchScope() {
+        if (on) {
+            (void)hipEventRecord(pe.stop, s->stream);
+            s->events.push_back(pe);
+        }
+    }
+};
+
+static void account(qsim_state *s, int kclass, double bytes) {
+    s->stats.launches++;
+    s->stats.algorithmic_bytes += bytes;
+    s->stats.k_launches[kclass]++;
+    s->stats.k_bytes[kclass] += bytes;
+}
+
+extern "C" int qsim_reset(qsim_state *s) {
+    if (!s) return fail(QSIM_ERR_ARG, "NULL state");
+    HIP_TRY(hipSetDevice(s->device));
+    s->queue.clear();
+    LaunchCfg cfg{s->stream, s->grid_cap};
+    {
+        LaunchScope scope(s, QSIM_K_INIT);
+        HIP_TRY(launch_init(cfg, s->amps, s->n));
+    }
+    account(s, QSIM_K_INIT, 16.0 * (double)(1ULL << s->n));
+    return QSIM_OK;
+}
+
+// ---- gate queue ----------------------------------------------------------------------------------------
+static int enqueue(qsim_state *s, const QueuedGate &g) {
+    s->queue.push_back(g);
+    s->stats.gates++;
+    if ((long)s->queue.size() >= s->max_pending) return qsim_flush(s);
+    return QSIM_OK;
+}
+
+extern "C" int qsim_apply_1q(qsim_state *s, const double *U, int target) {
+    if (!s || !U) return fail(QSIM_ERR_ARG, "NULL argument");
+    if (target < 0 || target >= s->n) return fail(QSIM_ERR_ARG, "qubit %d out of range (n = %d)", target, s->n);
+    QueuedGate g;
+    g.kind = QSIM_GATE_U1; g.q0 = target; g.q1 = -1;
+    for (int k = 0; k < 4; k++) g.m[k] = cd(U[2 * k], U[2 * k + 1]);
+    return enqueue(s, g);
+}
+
+extern "C" int qsim_apply_cx(qsim_state *s, int control, int target) {
+    if (!s) return fail(QSIM_ERR_ARG, "NULL state");
+    if (control < 0 || control >= s->n || target < 0 || target >= s->n)
+        return fail(QSIM_ERR_ARG, "cx operands (%d, %d) out of range (n = %d)", control, target, s->n);
+    QueuedGate g;
+    g.kind = QSIM_GATE_CX; g.q0 = control; g.q1 = target;
+    return enqueue(s, g);
+}
+
+extern "C" int qsim_apply_2q(qsim_state *s, const double *U, int q_hi, int q_lo) {
+    if (!s || !U) return fail(QSIM_ERR_ARG, "NULL argument");
+    if (q_lo < 0 || q_hi >= s->n || q_lo >= q_hi)
+        return fail(QSIM_ERR_ARG, "2q operands need 0 <= q_lo < q_hi < n (got %d, %d, n = %d)", q_hi, q_lo, s->n);
+    QueuedGate g;
+    g.kind = QSIM_GATE_U2; g.q0 = q_hi; g.q1 = q_lo;
+    for (int k = 0; k < 16; k++) g.m[k] = cd(U[2 * k], U[2 * k + 1]);
+    return enqueue(s, g);
+}
+
+// ---- scheduling + launch -------------------------------------------------------------------------------
+static SchedConfig sched_config(int n, int fuse, int tile_bits, int tile_low_bits, int tile_max_ops) {
+    SchedConfig c;
+    c.n = n; c.fuse = fuse; c.tile_bits = tile_bits; c.tile_low_bits = tile_low_bits; c.tile_max_ops = tile_max_ops;
+    return c;
+}
+
+static inline void to_m2(const FusedOp &op, M2 &u) {
+    for (int k = 0; k < 4; k++) { u.re[k] = op.m[k].real(); u.im[k] = op.m[k].imag(); }
+}
+static inline void to_m4(const FusedOp &op, M4 &u) {
+    for (int k = 0; k < 16; k++) { u.re[k] = op.m[k].real(); u.im[k] = op.m[k].imag(); }
+}
+
+// tile-local bit of global qubit q under geometry g
+static inline int local_bit(const TileGeom &g, int q) {
+    if (q < g.low_bits) return q;
+    for (int j = 0; j < g.n_high; j++)
+        if (g.high[j] == q) return g.low_bits + j;
+    return -1;
+}
+
+static void to_tile_op(const TileGeom &g, const FusedOp &op, TileOp &t) {
+    memset(&t, 0, sizeof t);
+    const bool diag = op.is_diag();
+    if (op.kind == OP_G1) {
+        t.b_hi = local_bit(g, op.q_hi);
+        if (diag) {
+            t.kind = TOP_DIAG1;
+            t.re[0] = op.m[0].real(); t.im[0] = op.m[0].imag();
+            t.re[1] = op.m[3].real(); t.im[1] = op.m[3].imag();
+        } else {
+            t.kind = TOP_G1;
+            for (int k = 0; k < 4; k++) { t.re[k] = op.m[k].real(); t.im[k] = op.m[k].imag(); }
+        }
+    } else {
+        t.b_hi = local_bit(g, op.q_hi);
+        t.b_lo = local_bit(g, op.q_lo);
+        if (diag) {
+            t.kind = TOP_DIAG2;
+            for (int k = 0; k < 4; k++) { t.re[k] = op.m[5 * k].real(); t.im[k] = op.m[5 * k].imag(); }
+        } else {
+            t.kind = TOP_G2;
+            for (int k = 0; k < 16; k++) { t.re[k] = op.m[k].real(); t.im[k] = op.m[k].imag(); }
+        }
+    }
+}
+
+static int launch_pass(qsim_state *s, const Pass &p) {
+    LaunchCfg cfg{s->stream, s->grid_cap};
+    const FusedOp &op = p.ops[0];
+    hipError_t e = hipSuccess;
+    switch (p.kclass) {
+    case QSIM_K_GATE1:
+    case QSIM_K_GATE1_LO: {
+        M2 u;
+        to_m2(op, u);
+        LaunchScope scope(s, p.kclass);
+        e = launch_gate1(cfg, s->amps, s->n, op.q_hi, u);
+        break;
+    }
+    case QSIM_K_PHASE: {
+        LaunchScope scope(s, p.kclass);
+        if (p.diag_full)
+            e = launch_diag1_full(cfg, s->amps, s->n, op.q_hi, op.m[0].real(), op.m[0].imag(), op.m[3].real(),
+                                  op.m[3].imag());
+        else
+            e = launch_phase(cfg, s->amps, s->n, op.q_hi, op.m[3].real(), op.m[3].imag());
+        break;
+    }
+    case QSIM_K_CX: {
+        LaunchScope scope(s, p.kclass);
+        e = launch_cx(cfg, s->amps, s->n, op.q_hi, op.q_lo);
+        break;
+    }
+    case QSIM_K_GATE2: {
+        M4 u;
+        to_m4(op, u);
+        LaunchScope scope(s, p.kclass);
+        e = launch_gate2(cfg, s->amps, s->n, op.q_hi, op.q_lo, u);
+        break;
+    }
+    case QSIM_K_TILE: {
+        const size_t need = p.ops.size();
+        if (need > s->ops_cap) return fail(QSIM_ERR_ARG, "tile pass with %zu ops exceeds the op buffer", need);
+        if (s->ops_used + need > s->ops_cap) { // ring is full: wait until earlier passes have read their ops
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            s->ops_used = 0;
+        }
+        TileOp *h = s->h_ops + s->ops_used;
+        for (size_t k = 0; k < need; k++) {
+            to_tile_op(p.geom, p.ops[k], h[k]);
+            if (h[k].b_hi < 0 || (p.ops[k].kind != OP_G1 && h[k].b_lo < 0))
+                return fail(QSIM_ERR_ARG, "internal: op qubit outside its tile");
+        }
+        TileOp *d = s->d_ops + s->ops_used;
+        HIP_TRY(hipMemcpyAsync(d, h, need * sizeof(TileOp), hipMemcpyHostToDevice, s->stream));
+        s->ops_used += need;
+        LaunchScope scope(s, p.kclass);
+        e = launch_tile(cfg, s->amps, p.geom, d, (int)need);
+        break;
+    }
+    default: return fail(QSIM_ERR_ARG, "internal: unknown kernel class %d", p.kclass);
+    }
+    if (e != hipSuccess) return fail(QSIM_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+    account(s, p.kclass, p.bytes);
+    return QSIM_OK;
+}
+
+extern "C" int qsim_flush(qsim_state *s) {
+    if (!s) return fail(QSIM_ERR_ARG, "NULL state");
+    if (s->queue.empty()) return QSIM_OK;
+    if (s->tile_bits - s->tile_low_bits < 2 || s->tile_bits - s->tile_low_bits > kMaxTileHigh)
+        return fail(QSIM_ERR_ARG, "tile_bits - tile_low_bits must be in 2..%d", kMaxTileHigh);
+    HIP_TRY(hipSetDevice(s->device));
+    Scheduler sched(sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops));
+    for (const QueuedGate &g : s->queue) {
+        if (g.kind == QSIM_GATE_U1) sched.add_1q(g.m, g.q0);
+        else if (g.kind == QSIM_GATE_CX) sched.add_cx(g.q0, g.q1);
+        else sched.add_2q(g.m, g.q0, g.q1);
+    }
+    s->queue.clear();
+    std::vector<Pass> passes;
+    sched.finish(passes);
+    for (const Pass &p : passes) {
+        const int rc = launch_pass(s, p);
+        if (rc) return rc;
+    }
+    return QSIM_OK;
+}
+
+extern "C" int qsim_sync(qsim_state *s) {
+    const int rc = qsim_flush(s);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return QSIM_OK;
+}
+
+// ---- amplitudes ----------------------------------------------------------------------------------------
+extern "C" int qsim_read(qsim_state *s, uint64_t first, uint64_t count, double *out) {
+    if (!s || !out) return fail(QSIM_ERR_ARG, "NULL argument");
+    const uint64_t N = 1ULL << s->n;
+    if (first > N || count > N - first) return fail(QSIM_ERR_ARG, "read range outside the state");
+    const int rc = qsim_sync(s);
+    if (rc) return rc;
+    if (count) HIP_TRY(hipMemcpy(out, s->amps + first, count * 16, hipMemcpyDeviceToHost));
+    return QSIM_OK;
+}
+
+extern "C" int qsim_write(qsim_state *s, uint64_t first, uint64_t count, const double *in) {
+    if (!s || !in) return fail(QSIM_ERR_ARG, "NULL argument");
+    const uint64_t N = 1ULL << s->n;
+    if (first > N || count > N - first) return fail(QSIM_ERR_ARG, "write range outside the state");
+    const int rc = qsim_sync(s);
+    if (rc) return rc;
+    if (count) HIP_TRY(hipMemcpy(s->amps + first, in, count * 16, hipMemcpyHostToDevice));
+    return QSIM_OK;
+}
+
+extern "C" int qsim_norm2(qsim_state *s, double *out) {
+    if (!s || !out) return fail(QSIM_ERR_ARG, "NULL argument");
+    const int rc = qsim_flush(s);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(s->d_scalar, 0, 8, s->stream));
+    LaunchCfg cfg{s->stream, s->grid_cap};
+    HIP_TRY(launch_norm2(cfg, s->amps, s->n, s->d_scalar));
+    HIP_TRY(hipMemcpyAsync(out, s->d_scalar, 8, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return QSIM_OK;
+}
+
+extern "C" int qsim_get_stats(qsim_state *s, qsim_stats *out) {
+    if (!s || !out) return fail(QSIM_ERR_ARG, "NULL argument");
+    const int rc = resolve_events(s);
+    if (rc) return rc;
+    *out = s->stats;
+    return QSIM_OK;
+}
+
+extern "C" int qsim_reset_stats(qsim_state *s) {
+    if (!s) return fail(QSIM_ERR_ARG, "NULL state");
+    const int rc = resolve_events(s);
+    if (rc) return rc;
+    memset(&s->stats, 0, sizeof s->stats);
+    return QSIM_OK;
+}
+
+// ---- circuits ------------------------------------------------------------------------------------------
+extern "C" int qsim_run_circuit(qsim_state *s, const qsim_circuit *c, long first, long count) {
+    if (!s || !c) return fail(QSIM_ERR_ARG, "NULL argument");
+    if (c->num_q != s->n) return fail(QSIM_ERR_ARG, "circuit has %d qubits, state has %d", c->num_q, s->n);
+    if (first < 0 || first > c->count) return fail(QSIM_ERR_ARG, "first gate %ld outside the circuit", first);
+    long end = count < 0 ? c->count : first + count;
+    if (end > c->count) end = c->count;
+    for (long i = first; i < end; i++) {
+        const qsim_gate_rec &g = c->gates[i];
+        int rc;
+        if (g.kind == QSIM_GATE_U1) rc = qsim_apply_1q(s, c->mats2 + 8 * (long)g.mat, g.q0);
+        else if (g.kind == QSIM_GATE_CX) rc = qsim_apply_cx(s, g.q0, g.q1);
+        else rc = qsim_apply_2q(s, c->mats4 + 32 * (long)g.mat, g.q0, g.q1);
+        if (rc) return rc;
+    }
+    return QSIM_OK;
+}
+
+static void feed(Scheduler &sched, const qsim_circuit *c) {
+    for (long i = 0; i < c->count; i++) {
+        const qsim_gate_rec &g = c->gates[i];
+        if (g.kind == QSIM_GATE_U1) {
+            cd m[4];
+            for (int k = 0; k < 4; k++) m[k] = cd(c->mats2[8 * (long)g.mat + 2 * k], c->mats2[8 * (long)g.mat + 2 * k + 1]);
+            sched.add_1q(m, g.q0);
+        } else if (g.kind == QSIM_GATE_CX) {
+            sched.add_cx(g.q0, g.q1);
+        } else {
+            cd m[16];
+            for (int k = 0; k < 16; k++) m[k] = cd(c->mats4[32 * (long)g.mat + 2 * k], c->mats4[32 * (long)g.mat + 2 * k + 1]);
+            sched.add_2q(m, g.q0, g.q1);
+        }
+    }
+}
+
+extern "C" int qsim_plan_circuit(const qsim_circuit *c, int fuse, int tile_bits, int tile_low_bits, qsim_stats *out) {
+    if (!c || !out) return fail(QSIM_ERR_ARG, "NULL argument");
+    if (fuse < 0 || fuse > 3) return fail(QSIM_ERR_ARG, "fuse level %d not in 0..3", fuse);
+    Scheduler sched(sched_config(c->num_q, fuse, tile_bits, tile_low_bits, 24));
+    feed(sched, c);
+    std::vector<Pass> passes;
+    sched.finish(passes);
+    memset(out, 0, sizeof *out);
+    out->gates = sched.gates_seen();
+    for (const Pass &p : passes) {
+        out->launches++;
+        out->algorithmic_bytes += p.bytes;
+        out->k_launches[p.kclass]++;
+        out->k_bytes[p.kclass] += p.bytes;
+    }
+    return QSIM_OK;
+}
+
+extern "C" int qsim_schedule_circuit(const qsim_circuit *c, int fuse, int tile_bits, int tile_low_bits, int tile_max_ops,
+                                     qsim_sched_cb cb, void *user) {
+    if (!c || !cb) return fail(QSIM_ERR_ARG, "NULL argument");
+    if (fuse < 0 || fuse > 3) return fail(QSIM_ERR_ARG, "fuse level %d not in 0..3", fuse);
+    Scheduler sched(sched_config(c->num_q, fuse, tile_bits, tile_low_bits, tile_max_ops));
+    feed(sched, c);
+    std::vector<Pass> passes;
+    sched.finish(passes);
+    int pi = 0;
+    for (const Pass &p : passes) {
+        for (const FusedOp &op : p.ops) {
+            double U[32];
+            const int cnt = op.kind == OP_G1 ? 4 : op.kind == OP_G2 ? 16 : 0;
+            for (int k = 0; k < cnt; k++) { U[2 * k] = op.m[k].real(); U[2 * k + 1] = op.m[k].imag(); }
+            if (p.kclass == QSIM_K_TILE) { // every op must lie inside the tile the pass declares
+                const bool in_hi = local_bit(p.geom, op.q_hi) >= 0;
+                const bool in_lo = op.kind == OP_G1 || local_bit(p.geom, op.q_lo) >= 0;
+                if (!in_hi || !in_lo) return fail(QSIM_ERR_ARG, "internal: op outside its tile");
+            }
+            const int kind = op.kind == OP_G1 ? QSIM_GATE_U1 : op.kind == OP_CX ? QSIM_GATE_CX : QSIM_GATE_U2;
+            cb(user, pi, p.kclass, kind, op.q_hi, op.q_lo, cnt ? U : nullptr, (int)op.gates);
+        }
+        pi++;
+    }
+    return QSIM_OK;
+}

@@ -1,0 +1,533 @@
+// kernels.hip — hand-written CDNA4 (gfx950) kernels for the state-vector hot path.
+//
+// State: 2^n amplitudes, fp64 complex, array-of-structs double2 (16 B) — one global_load_dwordx4 per
+// amplitude, 1 KiB per wave-instruction when lanes are consecutive.  Every kernel is HBM-bound by
+// design (0.44 flop/B for a dense 2x2, 0.94 flop/B for a dense 4x4; fp64 VALU peak is far above that),
+// so the rules that matter are: 16 B per lane, consecutive lanes on consecutive amplitudes, several
+// independent loads in flight per lane, no MFMA, no re-reads.
+//
+// What each kernel stands in for (file:line into the reference):
+//   k_init        init_state_vector                  quantum_simulator_naive.cu:64-70, quantum_simulator.c:175-177
+//   k_gate1_hi/lo execute_single_qubit_gate          quantum_simulator.c:81-92; kernel_gate naive.cu:72-95
+//   k_phase       same, for diag(1, lambda) gates    quantum_simulator.c:190-208 (z s sdg t tdg rz)
+//   k_cx          execute_cnot                       quantum_simulator.c:94-106; kernel_cnot naive.cu:97-122
+//   k_gate2_hh    kernel_gate_4                      quantum_simulator_4x4.cu:109-146
+//   k_tile        kernel_costant (whole op list in one launch, op data in constant/scalar memory)
+//                                                    quantum_simulator_preproces_constant.cu:169-178 — rebuilt
+//                                                    as a full-grid, LDS-tiled pass instead of one block
+// Index arithmetic is 64-bit throughout (the reference's `int th_id` stops at n = 31, naive.cu:74).
+#include "qsim_internal.h"
+
+namespace qsim {
+
+// Amplitudes travel as clang's native 2 x double vector: one global_load_dwordx4 / ds_read_b128 each and,
+// unlike the HIP_vector_type wrapper, a first-class value (arrays of it stay in registers).
+typedef double amp_t __attribute__((ext_vector_type(2)));
+static_assert(sizeof(amp_t) == sizeof(double2), "amp_t must alias double2");
+
+constexpr int TPB = 256;              // 4 waves of 64
+constexpr uint64_t kMaxGrid = 1u << 22; // beyond this the kernels loop (grid-stride over work tiles)
+
+__device__ __forceinline__ uint64_t insert_zero(uint64_t t, int q) {
+    return ((t >> q) << (q + 1)) | (t & ((1ULL << q) - 1ULL));
+}
+
+// r = a*u (complex), then r += b*w — written as explicit FMAs so hipcc keeps one v_fma_f64 each.
+__device__ __forceinline__ amp_t cmul(amp_t a, double ur, double ui) {
+    amp_t r;
+    r.x = fma(a.x, ur, -(a.y * ui));
+    r.y = fma(a.x, ui, a.y * ur);
+    return r;
+}
+__device__ __forceinline__ amp_t cfma(amp_t a, double ur, double ui, amp_t acc) {
+    amp_t r;
+    r.x = fma(a.x, ur, fma(-a.y, ui, acc.x));
+    r.y = fma(a.x, ui, fma(a.y, ur, acc.y));
+    return r;
+}
+__device__ __forceinline__ amp_t shfl_xor2(amp_t a, int mask) {
+    amp_t r;
+    r.x = __shfl_xor(a.x, mask, 64);
+    r.y = __shfl_xor(a.y, mask, 64);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// |0...0>
+__global__ __launch_bounds__(TPB) void k_init(amp_t *__restrict__ v, uint64_t N) {
+    const uint64_t stride = (uint64_t)gridDim.x * TPB;
+    for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < N; i += stride)
+        v[i] = amp_t{i == 0 ? 1.0 : 0.0, 0.0};
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Dense 2x2, target bit q >= 6.  Work item = amplitude pair (i0, i0 | 2^q); consecutive lanes take
+// consecutive i0, so each wave-instruction reads/writes one contiguous KiB from each of two streams
+// 2^q amplitudes apart.  IPT pairs per thread -> 2*IPT independent 16-B loads in flight per lane.
+template <int IPT, bool GUARD>
+__global__ __launch_bounds__(TPB) void k_gate1_hi(amp_t *__restrict__ v, uint64_t npairs, int q, M2 U,
+                                                  uint64_t ntiles) {
+    const uint64_t bit = 1ULL << q;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t t0 = tile * (uint64_t)(TPB * IPT) + threadIdx.x;
+        uint64_t i0[IPT];
+        amp_t a0[IPT], a1[IPT];
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            const uint64_t t = t0 + (uint64_t)k * TPB;
+            i0[k] = insert_zero(t, q);
+            if (!GUARD || t < npairs) {
+                a0[k] = v[i0[k]];
+                a1[k] = v[i0[k] | bit];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            const uint64_t t = t0 + (uint64_t)k * TPB;
+            if (!GUARD || t < npairs) {
+                v[i0[k]] = cfma(a1[k], U.re[1], U.im[1], cmul(a0[k], U.re[0], U.im[0]));
+                v[i0[k] | bit] = cfma(a1[k], U.re[3], U.im[3], cmul(a0[k], U.re[2], U.im[2]));
+            }
+        }
+    }
+}
+
+// Dense 2x2, target bit q < 6: both amplitudes of a pair sit in the same wave's contiguous KiB.  Each
+// lane loads its own amplitude (perfectly coalesced), fetches the partner's with a wave shuffle
+// (lane ^ 2^q — the butterfly), and computes its own output row.  Same flops per amplitude as the pair
+// form, no second pass, no LDS allocation.
+template <int IPT, bool GUARD>
+__global__ __launch_bounds__(TPB) void k_gate1_lo(amp_t *__restrict__ v, uint64_t N, int q, M2 U, uint64_t ntiles) {
+    const bool up = (threadIdx.x >> q) & 1; // bit q of the amplitude index == bit q of the lane id
+    const double own_r = up ? U.re[3] : U.re[0], own_i = up ? U.im[3] : U.im[0];
+    const double par_r = up ? U.re[2] : U.re[1], par_i = up ? U.im[2] : U.im[1];
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t i0 = tile * (uint64_t)(TPB * IPT) + threadIdx.x;
+        amp_t a[IPT];
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            const uint64_t i = i0 + (uint64_t)k * TPB;
+            a[k] = (!GUARD || i < N) ? v[i] : amp_t{0.0, 0.0};
+        }
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            const uint64_t i = i0 + (uint64_t)k * TPB;
+            const amp_t p = shfl_xor2(a[k], 1 << q);
+            const amp_t r = cfma(p, par_r, par_i, cmul(a[k], own_r, own_i));
+            if (!GUARD || i < N) v[i] = r;
+        }
+    }
+}
+
+// diag(1, lambda): only the bit=1 half is read and written (16*N bytes instead of 32*N).
+template <int IPT, bool GUARD>
+__global__ __launch_bounds__(TPB) void k_phase(amp_t *__restrict__ v, uint64_t nitems, int q, double lr, double li,
+                                               uint64_t ntiles) {
+    const uint64_t bit = 1ULL << q;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t t0 = tile * (uint64_t)(TPB * IPT) + threadIdx.x;
+        uint64_t idx[IPT];
+        amp_t a[IPT];
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            const uint64_t t = t0 + (uint64_t)k * TPB;
+            idx[k] = insert_zero(t, q) | bit;
+            if (!GUARD || t < nitems) a[k] = v[idx[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            const uint64_t t = t0 + (uint64_t)k * TPB;
+            if (!GUARD || t < nitems) v[idx[k]] = cmul(a[k], lr, li);
+        }
+    }
+}
+
+// diag(d0, d1) over every amplitude (used when d0 != 1, or when q < 2 makes the half form touch every
+// 64-B sector anyway).
+template <int IPT, bool GUARD>
+__global__ __launch_bounds__(TPB) void k_diag1_full(amp_t *__restrict__ v, uint64_t N, int q, double d0r, double d0i,
+                                                    double d1r, double d1i, uint64_t ntiles) {
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t i0 = tile * (uint64_t)(TPB * IPT) + threadIdx.x;
+        amp_t a[IPT];
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            const uint64_t i = i0 + (uint64_t)k * TPB;
+            if (!GUARD || i < N) a[k] = v[i];
+        }
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            const uint64_t i = i0 + (uint64_t)k * TPB;
+            const bool up = (i >> q) & 1;
+            if (!GUARD || i < N) v[i] = cmul(a[k], up ? d1r : d0r, up ? d1i : d0i);
+        }
+    }
+}
+
+// CX: swap v[i | c] <-> v[i | c | t] over the N/4 indices i with both bits clear.
+template <int IPT, bool GUARD>
+__global__ __launch_bounds__(TPB) void k_cx(amp_t *__restrict__ v, uint64_t nitems, int lo, int hi, uint64_t cbit,
+                                            uint64_t tbit, uint64_t ntiles) {
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t t0 = tile * (uint64_t)(TPB * IPT) + threadIdx.x;
+        uint64_t ia[IPT];
+        amp_t a[IPT], b[IPT];
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            const uint64_t t = t0 + (uint64_t)k * TPB;
+            ia[k] = insert_zero(insert_zero(t, lo), hi) | cbit;
+            if (!GUARD || t < nitems) {
+                a[k] = v[ia[k]];
+                b[k] = v[ia[k] | tbit];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            const uint64_t t = t0 + (uint64_t)k * TPB;
+            if (!GUARD || t < nitems) {
+                v[ia[k]] = b[k];
+                v[ia[k] | tbit] = a[k];
+            }
+        }
+    }
+}
+
+// Dense 4x4 with both target bits >= 6: four coalesced streams, all arithmetic in registers, matrix in
+// kernel arguments (scalar registers).  Row/column index = (bit hi, bit lo), row-major
+// (quantum_simulator_4x4.cu:119-134).
+template <int IPT, bool GUARD>
+__global__ __launch_bounds__(TPB) void k_gate2_hh(amp_t *__restrict__ v, uint64_t nitems, int lo, int hi, M4 U,
+                                                  uint64_t ntiles) {
+    const uint64_t blo = 1ULL << lo, bhi = 1ULL << hi;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t t0 = tile * (uint64_t)(TPB * IPT) + threadIdx.x;
+        uint64_t i00[IPT];
+        amp_t x[IPT][4];
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            const uint64_t t = t0 + (uint64_t)k * TPB;
+            i00[k] = insert_zero(insert_zero(t, lo), hi);
+            if (!GUARD || t < nitems) {
+                x[k][0] = v[i00[k]];
+                x[k][1] = v[i00[k] | blo];
+                x[k][2] = v[i00[k] | bhi];
+                x[k][3] = v[i00[k] | bhi | blo];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            const uint64_t t = t0 + (uint64_t)k * TPB;
+            if (!GUARD || t < nitems) {
+                amp_t y[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    amp_t acc = cmul(x[k][0], U.re[4 * r], U.im[4 * r]);
+#pragma unroll
+                    for (int c = 1; c < 4; c++) acc = cfma(x[k][c], U.re[4 * r + c], U.im[4 * r + c], acc);
+                    y[r] = acc;
+                }
+                v[i00[k]] = y[0];
+                v[i00[k] | blo] = y[1];
+                v[i00[k] | bhi] = y[2];
+                v[i00[k] | bhi | blo] = y[3];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Cache-blocked pass.  A tile is the 2^B amplitudes that agree on every index bit outside the tile set
+// T = {0..L-1} U {high[0..H-1]}; it is 2^H contiguous runs of 2^L amplitudes (16*2^L bytes each), so
+// global traffic stays in whole-KiB pieces whatever the high qubits are.  One workgroup stages a tile
+// in LDS, applies the whole op list to it (every op's qubits lie in T), and writes it back: one read
+// and one write of the state for n_ops fused blocks.  Op matrices are read with wave-uniform
+// addresses from a const __restrict__ buffer (scalar loads through the constant cache).
+//
+// Inside the tile an op on local bit b pairs LDS slots (i, i | 2^b); each pair/quad is owned by one
+// thread, so only a workgroup barrier between ops is needed.
+// Geometry as the kernel sees it: the high tile bits as a mask (no runtime-indexed arrays in device code).
+struct TileDev {
+    int32_t tile_bits, low_bits, n_high, n;
+    uint64_t high_mask; // global bit positions of tile-local bits L..B-1
+};
+
+// software PDEP: spreads the low bits of x over the set bits of mask, lowest first
+__device__ __forceinline__ uint64_t deposit(uint64_t x, uint64_t mask) {
+    uint64_t out = 0;
+    while (mask) {
+        const uint64_t low = mask & (0 - mask);
+        if (x & 1ULL) out |= low;
+        x >>= 1;
+        mask &= mask - 1;
+    }
+    return out;
+}
+
+// Op data is read through the CONSTANT address space with wave-uniform addresses, so hipcc emits scalar
+// loads (s_load_dwordx*): the matrix lives in SGPRs / the scalar cache, not in vector registers.
+typedef const TileOp __attribute__((address_space(4))) *ConstOps;
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_tile(amp_t *__restrict__ v, TileDev g, const TileOp *__restrict__ ops_g,
+                                                  int n_ops, uint64_t ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    amp_t *lds = reinterpret_cast<amp_t *>(smem);
+    const int B = g.tile_bits, L = g.low_bits, H = g.n_high;
+    uint64_t *hoff = reinterpret_cast<uint64_t *>(smem + ((size_t)16 << B));
+    ConstOps ops = (ConstOps)(uintptr_t)ops_g;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lowmask = (1u << L) - 1u;
+    const uint32_t E = 1u << B;
+    const uint64_t nmask = g.n >= 64 ? ~0ULL : ((1ULL << g.n) - 1ULL);
+    const uint64_t outer_mask = nmask & ~(g.high_mask | (uint64_t)lowmask);
+
+    for (uint32_t j = tid; j < (1u << H); j += THREADS) hoff[j] = deposit(j, g.high_mask);
+    __syncthreads();
+
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t base = deposit(tile, outer_mask); // wave-uniform
+
+        // stage in: CH independent 16-B loads in flight per lane, then CH LDS stores
+        constexpr int CH = 8;
+        for (uint32_t e0 = tid; e0 < E; e0 += THREADS * CH) {
+            amp_t r[CH];
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const uint32_t e = e0 + k * THREADS;
+                r[k] = e < E ? v[base | hoff[e >> L] | (uint64_t)(e & lowmask)] : amp_t{0.0, 0.0};
+            }
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const uint32_t e = e0 + k * THREADS;
+                if (e < E) lds[e] = r[k];
+            }
+        }
+        __syncthreads();
+
+        for (int oi = 0; oi < n_ops; oi++) {
+            const int kind = ops[oi].kind;
+            if (kind == TOP_G1) {
+                const int b = ops[oi].b_hi;
+                const double u0r = ops[oi].re[0], u0i = ops[oi].im[0], u1r = ops[oi].re[1], u1i = ops[oi].im[1];
+                const double u2r = ops[oi].re[2], u2i = ops[oi].im[2], u3r = ops[oi].re[3], u3i = ops[oi].im[3];
+#pragma unroll 4
+                for (uint32_t p = tid; p < (E >> 1); p += THREADS) {
+                    const uint32_t i0 = (uint32_t)insert_zero(p, b), i1 = i0 | (1u << b);
+                    const amp_t a0 = lds[i0], a1 = lds[i1];
+                    lds[i0] = cfma(a1, u1r, u1i, cmul(a0, u0r, u0i));
+                    lds[i1] = cfma(a1, u3r, u3i, cmul(a0, u2r, u2i));
+                }
+            } else if (kind == TOP_G2) {
+                const int bl = ops[oi].b_lo, bh = ops[oi].b_hi;
+                double ur[16], ui[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) { ur[k] = ops[oi].re[k]; ui[k] = ops[oi].im[k]; }
+#pragma unroll 2
+                for (uint32_t p = tid; p < (E >> 2); p += THREADS) {
+                    const uint32_t i00 = (uint32_t)insert_zero(insert_zero(p, bl), bh);
+                    const uint32_t i01 = i00 | (1u << bl), i10 = i00 | (1u << bh), i11 = i10 | (1u << bl);
+                    const amp_t x0 = lds[i00], x1 = lds[i01], x2 = lds[i10], x3 = lds[i11];
+                    amp_t y[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        amp_t acc = cmul(x0, ur[4 * r], ui[4 * r]);
+                        acc = cfma(x1, ur[4 * r + 1], ui[4 * r + 1], acc);
+                        acc = cfma(x2, ur[4 * r + 2], ui[4 * r + 2], acc);
+                        acc = cfma(x3, ur[4 * r + 3], ui[4 * r + 3], acc);
+                        y[r] = acc;
+                    }
+                    lds[i00] = y[0];
+                    lds[i01] = y[1];
+                    lds[i10] = y[2];
+                    lds[i11] = y[3];
+                }
+            } else if (kind == TOP_DIAG1) {
+                const int b = ops[oi].b_hi;
+                const double d0r = ops[oi].re[0], d0i = ops[oi].im[0], d1r = ops[oi].re[1], d1i = ops[oi].im[1];
+#pragma unroll 4
+                for (uint32_t e = tid; e < E; e += THREADS) {
+                    const bool up = (e >> b) & 1u;
+                    lds[e] = cmul(lds[e], up ? d1r : d0r, up ? d1i : d0i);
+                }
+            } else { // TOP_DIAG2
+                const int bl = ops[oi].b_lo, bh = ops[oi].b_hi;
+                const double e0r = ops[oi].re[0], e0i = ops[oi].im[0], e1r = ops[oi].re[1], e1i = ops[oi].im[1];
+                const double e2r = ops[oi].re[2], e2i = ops[oi].im[2], e3r = ops[oi].re[3], e3i = ops[oi].im[3];
+#pragma unroll 4
+                for (uint32_t e = tid; e < E; e += THREADS) {
+                    const bool hi = (e >> bh) & 1u, lo = (e >> bl) & 1u;
+                    const double dr = hi ? (lo ? e3r : e2r) : (lo ? e1r : e0r);
+                    const double di = hi ? (lo ? e3i : e2i) : (lo ? e1i : e0i);
+                    lds[e] = cmul(lds[e], dr, di);
+                }
+            }
+            __syncthreads();
+        }
+
+        // stage out
+        for (uint32_t e0 = tid; e0 < E; e0 += THREADS * CH) {
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const uint32_t e = e0 + k * THREADS;
+                if (e < E) v[base | hoff[e >> L] | (uint64_t)(e & lowmask)] = lds[e];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_norm2(const amp_t *__restrict__ v, uint64_t N, double *out) {
+    double acc = 0.0;
+    const uint64_t stride = (uint64_t)gridDim.x * TPB;
+    for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < N; i += stride) {
+        const amp_t a = v[i];
+        acc = fma(a.x, a.x, fma(a.y, a.y, acc));
+    }
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    __shared__ double part[TPB / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < TPB / 64; w++) s += part[w];
+        atomicAdd(out, s);
+    }
+}
+
+// Shard re-layout ahead of a global<->local qubit exchange: gathers so that the p selected index bits
+// become the top p bits (the destination block id) while the other bits keep their order.  Writes are
+// fully coalesced; reads come in runs of 2^bits[0] amplitudes.
+// Selected bits arrive as a mask; block bit j goes to the j-th lowest set bit.
+template <int IPT>
+__global__ __launch_bounds__(TPB) void k_pack(const amp_t *__restrict__ in, amp_t *__restrict__ out, uint64_t N, int n,
+                                              int p, uint64_t sel_mask, uint64_t ntiles) {
+    const int rest_bits = n - p;
+    const uint64_t rest_mask = (1ULL << rest_bits) - 1ULL;
+    const uint64_t nmask = n >= 64 ? ~0ULL : ((1ULL << n) - 1ULL);
+    const uint64_t keep_mask = nmask & ~sel_mask;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t d0 = tile * (uint64_t)(TPB * IPT) + threadIdx.x;
+        amp_t a[IPT];
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            const uint64_t d = d0 + (uint64_t)k * TPB;
+            a[k] = d < N ? in[deposit(d & rest_mask, keep_mask) | deposit(d >> rest_bits, sel_mask)] : amp_t{0.0, 0.0};
+        }
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            const uint64_t d = d0 + (uint64_t)k * TPB;
+            if (d < N) out[d] = a[k];
+        }
+    }
+}
+
+// ===================================================================================================
+// launchers
+static inline uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+static inline unsigned grid_for(const LaunchCfg &cfg, uint64_t ntiles) {
+    uint64_t g = ntiles;
+    if (cfg.grid_cap > 0 && g > (uint64_t)cfg.grid_cap) g = (uint64_t)cfg.grid_cap;
+    if (g > kMaxGrid) g = kMaxGrid;
+    return (unsigned)(g ? g : 1);
+}
+
+hipError_t launch_init(const LaunchCfg &cfg, double2 *v, int n) {
+    const uint64_t N = 1ULL << n;
+    uint64_t blocks = ceil_div(N, TPB);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_init, dim3((unsigned)blocks), dim3(TPB), 0, cfg.stream, (amp_t *)v, N);
+    return hipGetLastError();
+}
+
+#define QSIM_DISPATCH_GUARD(KERN, IPT, items, ...)                                                                    \
+    do {                                                                                                              \
+        const uint64_t nt_ = ceil_div((items), (uint64_t)TPB * (IPT));                                                \
+        if ((items) % ((uint64_t)TPB * (IPT)) == 0)                                                                   \
+            hipLaunchKernelGGL((KERN<IPT, false>), dim3(grid_for(cfg, nt_)), dim3(TPB), 0, cfg.stream, __VA_ARGS__,    \
+                               nt_);                                                                                  \
+        else                                                                                                          \
+            hipLaunchKernelGGL((KERN<IPT, true>), dim3(grid_for(cfg, nt_)), dim3(TPB), 0, cfg.stream, __VA_ARGS__,     \
+                               nt_);                                                                                  \
+    } while (0)
+
+hipError_t launch_gate1(const LaunchCfg &cfg, double2 *v, int n, int q, const M2 &U) {
+    const uint64_t N = 1ULL << n;
+    if (q >= 6) {
+        const uint64_t npairs = N >> 1;
+        QSIM_DISPATCH_GUARD(k_gate1_hi, 4, npairs, (amp_t *)v, npairs, q, U);
+    } else {
+        QSIM_DISPATCH_GUARD(k_gate1_lo, 4, N, (amp_t *)v, N, q, U);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_phase(const LaunchCfg &cfg, double2 *v, int n, int q, double lr, double li) {
+    const uint64_t items = (1ULL << n) >> 1;
+    QSIM_DISPATCH_GUARD(k_phase, 4, items, (amp_t *)v, items, q, lr, li);
+    return hipGetLastError();
+}
+
+hipError_t launch_diag1_full(const LaunchCfg &cfg, double2 *v, int n, int q, double d0r, double d0i, double d1r,
+                             double d1i) {
+    const uint64_t N = 1ULL << n;
+    QSIM_DISPATCH_GUARD(k_diag1_full, 4, N, (amp_t *)v, N, q, d0r, d0i, d1r, d1i);
+    return hipGetLastError();
+}
+
+hipError_t launch_cx(const LaunchCfg &cfg, double2 *v, int n, int control, int target) {
+    if (control == target) return hipSuccess; // quantum_simulator.c:99 — no index qualifies
+    const uint64_t items = (1ULL << n) >> 2;
+    const int lo = control < target ? control : target, hi = control < target ? target : control;
+    const uint64_t cbit = 1ULL << control, tbit = 1ULL << target;
+    QSIM_DISPATCH_GUARD(k_cx, 4, items, (amp_t *)v, items, lo, hi, cbit, tbit);
+    return hipGetLastError();
+}
+
+hipError_t launch_gate2(const LaunchCfg &cfg, double2 *v, int n, int q_hi, int q_lo, const M4 &U) {
+    const uint64_t items = (1ULL << n) >> 2;
+    QSIM_DISPATCH_GUARD(k_gate2_hh, 2, items, (amp_t *)v, items, q_lo, q_hi, U);
+    return hipGetLastError();
+}
+
+int tile_lds_bytes(int tile_bits) { return (16 << tile_bits) + (8 << kMaxTileHigh); }
+
+hipError_t launch_tile(const LaunchCfg &cfg, double2 *v, const TileGeom &g, const TileOp *d_ops, int n_ops) {
+    const uint64_t ntiles = 1ULL << (g.n - g.tile_bits);
+    const int lds = tile_lds_bytes(g.tile_bits);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<TPB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    TileDev td;
+    td.tile_bits = g.tile_bits; td.low_bits = g.low_bits; td.n_high = g.n_high; td.n = g.n;
+    td.high_mask = 0;
+    for (int j = 0; j < g.n_high; j++) td.high_mask |= 1ULL << g.high[j];
+    hipLaunchKernelGGL(k_tile<TPB>, dim3(grid_for(cfg, ntiles)), dim3(TPB), lds, cfg.stream, (amp_t *)v, td, d_ops, n_ops,
+                       ntiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_norm2(const LaunchCfg &cfg, const double2 *v, int n, double *d_out) {
+    const uint64_t N = 1ULL << n;
+    uint64_t blocks = ceil_div(N, (uint64_t)TPB * 8);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_norm2, dim3((unsigned)blocks), dim3(TPB), 0, cfg.stream, (const amp_t *)v, N, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack(const LaunchCfg &cfg, const double2 *in, double2 *out, int n, const int *bits, int p) {
+    uint64_t sel = 0;
+    for (int j = 0; j < p; j++) sel |= 1ULL << bits[j];
+    const uint64_t N = 1ULL << n;
+    const uint64_t nt = ceil_div(N, (uint64_t)TPB * 4);
+    hipLaunchKernelGGL(k_pack<4>, dim3(grid_for(cfg, nt)), dim3(TPB), 0, cfg.stream, (const amp_t *)in, (amp_t *)out, N, n, p,
+                       sel, nt);
+    return hipGetLastError();
+}
+
+} // namespace qsim

@@ -1,0 +1,100 @@
+/*
+ * main.c — `qsim <circuit_file> [number_of_measurement]`: the C host, drop-in for the CLI of
+ * quantum_simulator.c:32-79 (and of the CUDA variants, which take the file only, naive.cu:135-139).
+ *
+ * stdout is exactly what the reference prints: one "%lf\n" line with the elapsed seconds (parse + gates
+ * + device sync; file open, allocation of the result copy and any dump are outside, as :143,:244 place
+ * the timer), or the reference's error texts with exit code 1.  Everything else is opt-in through the
+ * environment and goes to files / stderr so scripts in the style of tester.bash keep working:
+ *   QSIM_DUMP=<path>       raw little-endian doubles (re, im) of all 2^n amplitudes
+ *   QSIM_DUMP_TEXT=<path>  "<index> <re> <im>" with %.17g, one amplitude per line
+ *   QSIM_STATS=1           one JSON line on stderr: gates, launches, algorithmic bytes, GB/s
+ *   QSIM_DEVICE, QSIM_FUSE, QSIM_TILE_BITS, QSIM_TILE_LOW_BITS, QSIM_TILE_MAX_OPS, QSIM_GRID_CAP, QSIM_PROFILE
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+
+#include "../../include/qsim.h"
+
+int qsim_apply_env_options(qsim_state *s);
+void qsim_print_format_help(const char *first_line);
+int qsim_dump_raw(qsim_state *s, const char *path);
+
+static double wall_seconds(void) {
+    struct timeval tv;
+    gettimeofday(&tv, NULL);
+    return (double)tv.tv_sec + (double)tv.tv_usec * 1e-6;
+}
+
+static int dump_text(qsim_state *s, const char *path) {
+    const int n = qsim_num_qubits(s);
+    const uint64_t N = 1ULL << n, chunk = N < (1ULL << 20) ? N : (1ULL << 20);
+    double *buf = (double *)malloc((size_t)chunk * 16);
+    FILE *f = fopen(path, "w");
+    int rc = (buf && f) ? QSIM_OK : QSIM_ERR_ALLOC;
+    for (uint64_t at = 0; rc == QSIM_OK && at < N; at += chunk) {
+        rc = qsim_read(s, at, chunk, buf);
+        for (uint64_t i = 0; rc == QSIM_OK && i < chunk; i++)
+            fprintf(f, "%llu %.17g %.17g\n", (unsigned long long)(at + i), buf[2 * i], buf[2 * i + 1]);
+    }
+    if (f) fclose(f);
+    free(buf);
+    return rc;
+}
+
+int main(int argc, char *argv[]) {
+    if (argc < 2) { /* quantum_simulator.c:39-43 */
+        printf("QUANTUM CIRCUIT SIMULATOR\n");
+        printf("Usage: %s <circuit_file_name> <number_of_measurement>\n", argv[0]);
+        exit(1);
+    }
+    const char *v;
+    qsim_circuit *c = NULL;
+    qsim_state *s = NULL;
+
+    const double t_start = wall_seconds();
+    int rc = qsim_circuit_parse_file(argv[1], &c);
+    if (rc == QSIM_ERR_OPEN) {
+        printf("ERROR: cannot open circuit file\n");
+        exit(1);
+    }
+    if (rc != QSIM_OK) {
+        qsim_print_format_help(qsim_circuit_error());
+        printf("ERROR while parsing quantum circuit\n"); /* :55-58 */
+        exit(1);
+    }
+    const int device = (v = getenv("QSIM_DEVICE")) && *v ? atoi(v) : 0;
+    rc = qsim_create(&s, qsim_circuit_num_qubits(c), device);
+    if (rc == QSIM_OK) rc = qsim_apply_env_options(s);
+    if (rc == QSIM_OK) rc = qsim_run_circuit(s, c, 0, -1);
+    if (rc == QSIM_OK) rc = qsim_sync(s);
+    if (rc != QSIM_OK) {
+        if (rc == QSIM_ERR_ALLOC) printf("Malloc error\n"); /* :170 */
+        else printf("ERROR: %s\n", qsim_last_error());
+        printf("ERROR while parsing quantum circuit\n");
+        exit(1);
+    }
+    const double t_exe = wall_seconds() - t_start;
+    printf("%lf\n", t_exe); /* :248 */
+    fflush(stdout);
+
+    if ((v = getenv("QSIM_DUMP")) && *v && qsim_dump_raw(s, v) != QSIM_OK) fprintf(stderr, "qsim: dump failed: %s\n", qsim_last_error());
+    if ((v = getenv("QSIM_DUMP_TEXT")) && *v && dump_text(s, v) != QSIM_OK) fprintf(stderr, "qsim: dump failed: %s\n", qsim_last_error());
+    if ((v = getenv("QSIM_STATS")) && *v && atoi(v)) {
+        qsim_stats st;
+        if (qsim_get_stats(s, &st) == QSIM_OK) {
+            double kms = 0;
+            for (int k = 1; k < QSIM_K_COUNT; k++) kms += st.k_ms[k];
+            fprintf(stderr,
+                    "{\"qubits\": %d, \"gates\": %llu, \"launches\": %llu, \"algorithmic_bytes\": %.0f, "
+                    "\"seconds\": %.6f, \"gate_applies_per_s\": %.3f, \"kernel_ms\": %.3f}\n",
+                    qsim_num_qubits(s), (unsigned long long)st.gates, (unsigned long long)st.launches,
+                    st.algorithmic_bytes, t_exe, t_exe > 0 ? (double)st.gates / t_exe : 0.0, kms);
+        }
+    }
+    qsim_circuit_free(c);
+    qsim_destroy(s);
+    return 0;
+}

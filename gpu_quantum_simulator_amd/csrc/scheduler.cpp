@@ -1,0 +1,278 @@
+// scheduler.cpp — see scheduler.h.  Pure host code; compiled into libqsim.so and exercised on the CPU by
+// tests/test_scheduler_cpu.py through qsim_schedule_circuit().
+#include "scheduler.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace qsim {
+
+static const cd kI2[4] = {cd(1, 0), cd(0, 0), cd(0, 0), cd(1, 0)};
+
+static inline bool is_zero(const cd &z) { return z.real() == 0.0 && z.imag() == 0.0; }
+static inline bool is_one(const cd &z) { return z.real() == 1.0 && z.imag() == 0.0; }
+
+bool FusedOp::is_diag() const {
+    if (kind == OP_G1) return is_zero(m[1]) && is_zero(m[2]);
+    if (kind == OP_G2) {
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++)
+                if (r != c && !is_zero(m[4 * r + c])) return false;
+        return true;
+    }
+    return false;
+}
+
+// EXACT identity only: the reference's isIdentity tolerance of 1e-3 (quantum_simulator_4x4.cu:247-250)
+// silently drops and reorders small rotations.
+bool FusedOp::is_identity() const {
+    if (!is_diag()) return false;
+    const int d = kind == OP_G1 ? 2 : 4;
+    for (int r = 0; r < d; r++)
+        if (!is_one(m[(d + 1) * r])) return false;
+    return true;
+}
+
+// ---- fusion algebra (own formulation of quantum_simulator_4x4.cu:148-233) -----------------------------
+void Scheduler::mul2(const cd a[4], const cd b[4], cd out[4]) {
+    cd t[4];
+    for (int r = 0; r < 2; r++)
+        for (int c = 0; c < 2; c++) t[2 * r + c] = a[2 * r] * b[c] + a[2 * r + 1] * b[2 + c];
+    std::copy(t, t + 4, out);
+}
+
+void Scheduler::mul4(const cd a[16], const cd b[16], cd out[16]) {
+    cd t[16];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+            cd s(0, 0);
+            for (int k = 0; k < 4; k++) s += a[4 * r + k] * b[4 * k + c];
+            t[4 * r + c] = s;
+        }
+    std::copy(t, t + 16, out);
+}
+
+// (hi (x) lo)[(i1 i2), (j1 j2)] = hi[i1][j1] * lo[i2][j2]
+void Scheduler::kron(const cd hi[4], const cd lo[4], cd out[16]) {
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) out[4 * r + c] = hi[2 * (r >> 1) + (c >> 1)] * lo[2 * (r & 1) + (c & 1)];
+}
+
+// CX as a permutation of the basis |hi lo>: control on the high bit exchanges |10> and |11>, control on
+// the low bit exchanges |01> and |11>.
+void Scheduler::cx4(bool control_is_hi, cd out[16]) {
+    const int perm_hi[4] = {0, 1, 3, 2}, perm_lo[4] = {0, 3, 2, 1};
+    const int *p = control_is_hi ? perm_hi : perm_lo;
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) out[4 * r + c] = cd(p[r] == c ? 1.0 : 0.0, 0.0);
+}
+
+// std::complex multiplication may go through the Annex-G slow path; these matrices are tiny and only
+// built on the host, so that is irrelevant.  Zeros stay exact: every term of an off-diagonal entry of a
+// product of diagonal matrices has an exact-zero factor.
+
+Scheduler::Scheduler(const SchedConfig &cfg) : cfg_(cfg), open_(cfg.n > 0 ? cfg.n : 0, -1) {}
+
+void Scheduler::close(int idx) {
+    if (idx < 0) return;
+    FusedOp &op = pool_[idx];
+    open_[op.q_hi] = -1;
+    if (op.kind == OP_G2) open_[op.q_lo] = -1;
+    if (!op.is_identity()) closed_.push_back(op);
+    op.kind = 0;
+}
+
+void Scheduler::add_1q(const cd U[4], int q) {
+    gates_++;
+    if (cfg_.fuse == 0) {
+        FusedOp op;
+        op.kind = OP_G1; op.q_hi = q; op.gates = 1;
+        std::copy(U, U + 4, op.m);
+        closed_.push_back(op);
+        return;
+    }
+    const int idx = open_[q];
+    if (idx < 0) {
+        FusedOp op;
+        op.kind = OP_G1; op.q_hi = q; op.gates = 1;
+        std::copy(U, U + 4, op.m);
+        pool_.push_back(op);
+        open_[q] = (int)pool_.size() - 1;
+        return;
+    }
+    FusedOp &c = pool_[idx];
+    c.gates++;
+    if (c.kind == OP_G1) {
+        mul2(U, c.m, c.m); // later gate multiplies from the left
+    } else {
+        cd e[16];
+        if (q == c.q_hi) kron(U, kI2, e);
+        else kron(kI2, U, e);
+        mul4(e, c.m, c.m);
+    }
+}
+
+void Scheduler::add_cx(int control, int target) {
+    gates_++;
+    if (control == target) return; // quantum_simulator.c:99: a silent no-op
+    if (cfg_.fuse <= 1) {
+        if (cfg_.fuse == 1) { close(open_[control]); close(open_[target]); }
+        FusedOp op;
+        op.kind = OP_CX; op.q_hi = control; op.q_lo = target; op.gates = 1;
+        closed_.push_back(op);
+        return;
+    }
+    cd m[16];
+    cx4(control > target, m);
+    fold_2q(m, std::max(control, target), std::min(control, target), 1);
+}
+
+void Scheduler::add_2q(const cd U[16], int q_hi, int q_lo) {
+    gates_++;
+    if (cfg_.fuse <= 1) {
+        if (cfg_.fuse == 1) { close(open_[q_hi]); close(open_[q_lo]); }
+        FusedOp op;
+        op.kind = OP_G2; op.q_hi = q_hi; op.q_lo = q_lo; op.gates = 1;
+        std::copy(U, U + 16, op.m);
+        closed_.push_back(op);
+        return;
+    }
+    fold_2q(U, q_hi, q_lo, 1);
+}
+
+void Scheduler::fold_2q(const cd U[16], int q_hi, int q_lo, uint32_t gates) {
+    int ia = open_[q_hi], ib = open_[q_lo];
+    if (ia >= 0 && ia == ib) { // the pair is already one cluster: keep folding
+        FusedOp &c = pool_[ia];
+        mul4(U, c.m, c.m);
+        c.gates += gates;
+        return;
+    }
+    // a cluster shared with a third qubit has to run first
+    if (ia >= 0 && pool_[ia].kind == OP_G2) { close(ia); ia = -1; }
+    if (ib >= 0 && pool_[ib].kind == OP_G2) { close(ib); ib = -1; }
+    FusedOp op;
+    op.kind = OP_G2; op.q_hi = q_hi; op.q_lo = q_lo; op.gates = gates;
+    const cd *a = kI2, *b = kI2;
+    if (ia >= 0) { a = pool_[ia].m; op.gates += pool_[ia].gates; }
+    if (ib >= 0) { b = pool_[ib].m; op.gates += pool_[ib].gates; }
+    cd k[16];
+    kron(a, b, k);
+    mul4(U, k, op.m);
+    if (ia >= 0) pool_[ia].kind = 0;
+    if (ib >= 0) pool_[ib].kind = 0;
+    pool_.push_back(op);
+    open_[q_hi] = open_[q_lo] = (int)pool_.size() - 1;
+}
+
+void Scheduler::finish(std::vector<Pass> &out) {
+    for (int q = 0; q < cfg_.n; q++) close(open_[q]);
+    pool_.clear();
+    build_passes(out);
+    closed_.clear();
+}
+
+// ---- pass construction --------------------------------------------------------------------------------
+void Scheduler::single_op_pass(const FusedOp &op, std::vector<Pass> &out) const {
+    const double S = 16.0 * (double)(1ULL << cfg_.n); // bytes of state
+    Pass p;
+    p.ops.push_back(op);
+    if (op.kind == OP_G1) {
+        if (op.is_identity()) return;
+        if (op.is_diag()) {
+            p.kclass = QSIM_K_PHASE;
+            const bool unit0 = is_one(op.m[0]);
+            p.diag_full = !unit0 || op.q_hi < 2; // below 64-B runs every sector is touched anyway
+            p.bytes = unit0 ? S : 2 * S;
+        } else {
+            p.kclass = op.q_hi >= 6 ? QSIM_K_GATE1 : QSIM_K_GATE1_LO;
+            p.bytes = 2 * S;
+        }
+        out.push_back(std::move(p));
+    } else if (op.kind == OP_CX) {
+        p.kclass = QSIM_K_CX;
+        p.bytes = S;
+        out.push_back(std::move(p));
+    } else {
+        if (op.is_identity()) return;
+        if (op.q_lo >= 6) {
+            p.kclass = QSIM_K_GATE2;
+            p.bytes = 2 * S;
+            out.push_back(std::move(p));
+        } else {
+            tile_pass(p.ops, out);
+        }
+    }
+}
+
+void Scheduler::tile_pass(const std::vector<FusedOp> &ops, std::vector<Pass> &out) const {
+    const int B = std::min(cfg_.tile_bits, cfg_.n);
+    const int L = std::min(cfg_.tile_low_bits, B);
+    Pass p;
+    p.kclass = QSIM_K_TILE;
+    p.ops = ops;
+    p.bytes = 32.0 * (double)(1ULL << cfg_.n);
+    uint64_t high = 0;
+    for (const FusedOp &op : ops) {
+        if (op.q_hi >= L) high |= 1ULL << op.q_hi;
+        if (op.kind != OP_G1 && op.q_lo >= L) high |= 1ULL << op.q_lo;
+    }
+    // unused slots take the lowest free bits: longer contiguous runs for the same LDS footprint
+    for (int b = L; b < cfg_.n && __builtin_popcountll(high) < B - L; b++) high |= 1ULL << b;
+    p.geom.tile_bits = L + __builtin_popcountll(high);
+    p.geom.low_bits = L;
+    p.geom.n = cfg_.n;
+    p.geom.n_high = 0;
+    for (int b = L; b < cfg_.n; b++)
+        if (high >> b & 1ULL) p.geom.high[p.geom.n_high++] = b;
+    out.push_back(std::move(p));
+}
+
+void Scheduler::build_passes(std::vector<Pass> &out) {
+    if (cfg_.fuse <= 2) {
+        for (const FusedOp &op : closed_) single_op_pass(op, out);
+        return;
+    }
+    const int B = std::min(cfg_.tile_bits, cfg_.n);
+    const int L = std::min(cfg_.tile_low_bits, B);
+    const int kmax = std::min(B - L, (int)kMaxTileHigh);
+    const uint64_t lowmask = (1ULL << L) - 1ULL;
+    const uint64_t all = cfg_.n >= 64 ? ~0ULL : ((1ULL << cfg_.n) - 1ULL);
+    const size_t m = closed_.size();
+    std::vector<char> done(m, 0);
+    size_t first = 0;
+    std::vector<FusedOp> group;
+    while (first < m) {
+        if (done[first]) { first++; continue; }
+        group.clear();
+        uint64_t hset = 0, blocked = 0;
+        const size_t end = std::min(m, first + (size_t)cfg_.window);
+        for (size_t i = first; i < end; i++) {
+            if (done[i]) continue;
+            const FusedOp &op = closed_[i];
+            uint64_t qmask = 1ULL << op.q_hi;
+            if (op.kind != OP_G1) qmask |= 1ULL << op.q_lo;
+            if (qmask & blocked) { blocked |= qmask; continue; }
+            const uint64_t need = qmask & ~lowmask & ~hset;
+            if (__builtin_popcountll(hset) + __builtin_popcountll(need) <= kmax &&
+                (int)group.size() < cfg_.tile_max_ops) {
+                group.push_back(op);
+                hset |= need;
+                done[i] = 1;
+            } else {
+                blocked |= qmask;
+            }
+            if (blocked == all) break;
+        }
+        if (group.empty()) { // cannot happen while kmax >= 2; keep the scheduler total anyway
+            single_op_pass(closed_[first], out);
+            done[first] = 1;
+        } else if (group.size() == 1) {
+            single_op_pass(group[0], out);
+        } else {
+            tile_pass(group, out);
+        }
+    }
+}
+
+} // namespace qsim

@@ -1,0 +1,84 @@
+// scheduler.h — host-side gate scheduler (no device code): turns the queued gate stream into passes.
+//
+// Reference rows: a10 fusion algebra (quantum_simulator_4x4.cu:148-250: mm2x2, mm4x4,
+// tensorProd, cnotTo4x4), a11 pair state machine (quantum_simulator_4x4.cu:327-501; 2x2-only form
+// quantum_simulator_preproces.cu:215-269), a12 op list for a single launch
+// (quantum_simulator_preproces_constant.cu:288-369).  The algorithms here are this project's own:
+// clusters are folded eagerly (no separate pending 2x2 per paired qubit), identity tests are EXACT
+// (the reference's 1e-3 tolerance reorders gates), and level 3 groups clusters into
+// cache-blocked passes by a greedy scan over the dependency order.
+#ifndef QSIM_SCHEDULER_H
+#define QSIM_SCHEDULER_H
+
+#include <complex>
+#include <cstdint>
+#include <vector>
+
+#include "qsim_internal.h"
+
+namespace qsim {
+
+using cd = std::complex<double>;
+
+enum OpKind : int { OP_G1 = 1, OP_CX = 2, OP_G2 = 3 };
+
+struct FusedOp {
+    int kind = 0;
+    int q_hi = -1; // OP_G1: target; OP_CX: control; OP_G2: high qubit
+    int q_lo = -1; // OP_CX: target; OP_G2: low qubit
+    cd m[16];      // OP_G1: 2x2 in m[0..3]; OP_G2: 4x4 row-major, index = (bit q_hi, bit q_lo)
+    uint32_t gates = 0;
+
+    bool is_diag() const;
+    bool is_identity() const;
+};
+
+struct Pass {
+    int kclass = 0;           // QSIM_K_*
+    std::vector<FusedOp> ops; // one op unless kclass == QSIM_K_TILE
+    TileGeom geom{};          // QSIM_K_TILE only
+    double bytes = 0;         // algorithmic bytes this pass must move
+    bool diag_full = false;   // QSIM_K_PHASE executed over every amplitude (d0 != 1 or q < 2)
+};
+
+struct SchedConfig {
+    int n = 0;
+    int fuse = 3;
+    int tile_bits = 12;
+    int tile_low_bits = 7;
+    int tile_max_ops = 24;
+    int window = 4096; // clusters scanned ahead when grouping a pass
+};
+
+class Scheduler {
+  public:
+    explicit Scheduler(const SchedConfig &cfg);
+    void add_1q(const cd U[4], int q);
+    void add_cx(int control, int target);
+    void add_2q(const cd U[16], int q_hi, int q_lo);
+    // Closes every open cluster and appends the passes for everything added so far.
+    void finish(std::vector<Pass> &out);
+    uint64_t gates_seen() const { return gates_; }
+
+    // fusion algebra, exposed for tests
+    static void mul2(const cd a[4], const cd b[4], cd out[4]);     // out = a*b
+    static void mul4(const cd a[16], const cd b[16], cd out[16]);  // out = a*b
+    static void kron(const cd hi[4], const cd lo[4], cd out[16]);  // out = hi (x) lo
+    static void cx4(bool control_is_hi, cd out[16]);
+
+  private:
+    SchedConfig cfg_;
+    uint64_t gates_ = 0;
+    std::vector<FusedOp> pool_;   // open clusters
+    std::vector<int> open_;       // per qubit: index into pool_, or -1
+    std::vector<FusedOp> closed_; // fused ops in a valid execution order
+
+    void close(int idx);
+    void fold_2q(const cd U[16], int q_hi, int q_lo, uint32_t gates);
+    void build_passes(std::vector<Pass> &out);
+    void single_op_pass(const FusedOp &op, std::vector<Pass> &out) const;
+    void tile_pass(const std::vector<FusedOp> &ops, std::vector<Pass> &out) const;
+};
+
+} // namespace qsim
+#endif

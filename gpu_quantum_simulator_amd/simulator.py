@@ -1,0 +1,243 @@
+"""Python mirror of the C host: thin objects over the C ABI handles, nothing computed in Python.
+
+`Circuit` = qsim_circuit (the tokenizer of quantum_simulator.c:115-254 and the gate table :184-211),
+`Simulator` = qsim_state (state vector in HBM; execute_single_qubit_gate :81-92 -> apply_1q,
+execute_cnot :94-106 -> apply_cx, kernel_gate_4 quantum_simulator_4x4.cu:109-146 -> apply_2q).
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref, c_double, c_int, c_void_p
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import QsimStats, check
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(c_double))
+
+
+def _mat(U, dim: int) -> np.ndarray:
+    m = np.ascontiguousarray(np.asarray(U, dtype=np.complex128).reshape(dim * dim))
+    return m.view(np.float64)
+
+
+def gate_matrix(token: str) -> Optional[np.ndarray]:
+    """2x2 for a gate token of the reference's vocabulary (None for cx / unknown)."""
+    u = np.zeros(8)
+    kind = _lib.load().qsim_gate_matrix(token.encode(), _dp(u))
+    return u.view(np.complex128).reshape(2, 2).copy() if kind == _lib.GATE_U1 else None
+
+
+class Circuit:
+    def __init__(self, handle: c_void_p):
+        self._h = handle
+
+    @classmethod
+    def empty(cls, num_q: int) -> "Circuit":
+        h = c_void_p()
+        check(_lib.load().qsim_circuit_create(num_q, byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_file(cls, path: str) -> "Circuit":
+        h = c_void_p()
+        rc = _lib.load().qsim_circuit_parse_file(path.encode(), byref(h))
+        if rc:
+            raise _lib.QsimError(rc, (_lib.load().qsim_circuit_error() or b"").decode())
+        return cls(h)
+
+    @classmethod
+    def from_text(cls, text: str) -> "Circuit":
+        h = c_void_p()
+        raw = text.encode()
+        rc = _lib.load().qsim_circuit_parse_text(raw, len(raw), byref(h))
+        if rc:
+            raise _lib.QsimError(rc, (_lib.load().qsim_circuit_error() or b"").decode())
+        return cls(h)
+
+    @classmethod
+    def from_gates(cls, num_q: int, gates: Iterable[Sequence]) -> "Circuit":
+        """gates in the tuple form of circuits.random_gates."""
+        c = cls.empty(num_q)
+        cache = {}
+        for g in gates:
+            if g[0] == "cx":
+                c.append_cx(g[1], g[2])
+            elif g[0] == "rz":
+                c.append_1q(gate_matrix(f"rz({g[1]!r})"), g[2])
+            else:
+                if g[0] not in cache:
+                    cache[g[0]] = gate_matrix(g[0])
+                c.append_1q(cache[g[0]], g[1])
+        return c
+
+    def append_1q(self, U, target: int) -> None:
+        check(_lib.load().qsim_circuit_append_1q(self._h, _dp(_mat(U, 2)), target))
+
+    def append_cx(self, control: int, target: int) -> None:
+        check(_lib.load().qsim_circuit_append_cx(self._h, control, target))
+
+    def append_2q(self, U, q_hi: int, q_lo: int) -> None:
+        check(_lib.load().qsim_circuit_append_2q(self._h, _dp(_mat(U, 4)), q_hi, q_lo))
+
+    @property
+    def num_qubits(self) -> int:
+        return _lib.load().qsim_circuit_num_qubits(self._h)
+
+    def __len__(self) -> int:
+        return int(_lib.load().qsim_circuit_num_gates(self._h))
+
+    def gate(self, i: int):
+        kind, q0, q1 = c_int(), c_int(), c_int()
+        u = np.zeros(32)
+        check(_lib.load().qsim_circuit_gate(self._h, i, byref(kind), byref(q0), byref(q1), _dp(u)))
+        if kind.value == _lib.GATE_U1:
+            return ("u1", q0.value, u[:8].view(np.complex128).reshape(2, 2).copy())
+        if kind.value == _lib.GATE_CX:
+            return ("cx", q0.value, q1.value)
+        return ("u2", q0.value, q1.value, u.view(np.complex128).reshape(4, 4).copy())
+
+    def plan(self, fuse: int = 3, tile_bits: int = 12, tile_low_bits: int = 7) -> dict:
+        st = QsimStats()
+        check(_lib.load().qsim_plan_circuit(self._h, fuse, tile_bits, tile_low_bits, byref(st)))
+        return st.as_dict()
+
+    def schedule(self, fuse: int = 3, tile_bits: int = 12, tile_low_bits: int = 7, tile_max_ops: int = 24) -> list:
+        """Fused blocks in launch order: (pass, kernel_class, kind, q0, q1, matrix|None, gates_folded)."""
+        out = []
+
+        def cb(_user, pass_i, kclass, kind, q0, q1, U, folded):
+            m = None
+            if kind == _lib.GATE_U1:
+                m = np.ctypeslib.as_array(U, shape=(8,)).copy().view(np.complex128).reshape(2, 2)
+            elif kind == _lib.GATE_U2:
+                m = np.ctypeslib.as_array(U, shape=(32,)).copy().view(np.complex128).reshape(4, 4)
+            out.append((pass_i, _lib.K_NAMES[kclass], {1: "u1", 2: "cx", 3: "u2"}[kind], q0, q1, m, folded))
+
+        check(_lib.load().qsim_schedule_circuit(self._h, fuse, tile_bits, tile_low_bits, tile_max_ops,
+                                                _lib.SCHED_CB(cb), None))
+        return out
+
+    def close(self) -> None:
+        if self._h:
+            _lib.load().qsim_circuit_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Simulator:
+    """One state vector resident on one GPU."""
+
+    def __init__(self, num_q: int, device: int = 0, *, fuse: Optional[int] = None, profile: bool = False,
+                 external_ptr: Optional[int] = None, **options):
+        self._h = c_void_p()
+        lib = _lib.load()
+        if external_ptr is None:
+            check(lib.qsim_create(byref(self._h), num_q, device))
+        else:
+            check(lib.qsim_create_external(byref(self._h), num_q, device, c_void_p(external_ptr)))
+        self.num_qubits = num_q
+        if fuse is not None:
+            self.set_option(_lib.OPT_FUSE, fuse)
+        if profile:
+            self.set_option(_lib.OPT_PROFILE, 1)
+        names = {"tile_bits": _lib.OPT_TILE_BITS, "tile_low_bits": _lib.OPT_TILE_LOW_BITS,
+                 "max_pending": _lib.OPT_MAX_PENDING, "tile_max_ops": _lib.OPT_TILE_MAX_OPS,
+                 "grid_cap": _lib.OPT_GRID_CAP}
+        # tile_low_bits first when shrinking, tile_bits first when growing: keep every intermediate valid
+        for key in sorted(options, key=lambda k: k != "tile_low_bits"):
+            self.set_option(names[key], options[key])
+
+    # -- options / lifecycle
+    def set_option(self, opt: int, value: int) -> None:
+        check(_lib.load().qsim_set_option(self._h, opt, value))
+
+    def reset(self) -> None:
+        check(_lib.load().qsim_reset(self._h))
+
+    def close(self) -> None:
+        if self._h:
+            _lib.load().qsim_destroy(self._h)
+            self._h = c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- gates
+    def apply_1q(self, U, target: int) -> None:
+        check(_lib.load().qsim_apply_1q(self._h, _dp(_mat(U, 2)), target))
+
+    def apply_cx(self, control: int, target: int) -> None:
+        check(_lib.load().qsim_apply_cx(self._h, control, target))
+
+    def apply_2q(self, U, q_hi: int, q_lo: int) -> None:
+        check(_lib.load().qsim_apply_2q(self._h, _dp(_mat(U, 4)), q_hi, q_lo))
+
+    def run(self, circuit: Circuit, first: int = 0, count: int = -1) -> None:
+        check(_lib.load().qsim_run_circuit(self._h, circuit._h, first, count))
+
+    def flush(self) -> None:
+        check(_lib.load().qsim_flush(self._h))
+
+    def sync(self) -> None:
+        check(_lib.load().qsim_sync(self._h))
+
+    # -- amplitudes
+    def read(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        if count is None:
+            count = (1 << self.num_qubits) - first
+        out = np.empty(2 * count, dtype=np.float64)
+        check(_lib.load().qsim_read(self._h, first, count, _dp(out)))
+        return out.view(np.complex128)
+
+    def write(self, amps: np.ndarray, first: int = 0) -> None:
+        a = np.ascontiguousarray(amps, dtype=np.complex128)
+        check(_lib.load().qsim_write(self._h, first, a.size, _dp(a.view(np.float64))))
+
+    def norm2(self) -> float:
+        v = c_double()
+        check(_lib.load().qsim_norm2(self._h, byref(v)))
+        return v.value
+
+    @property
+    def device_ptr(self) -> int:
+        return int(_lib.load().qsim_device_ptr(self._h) or 0)
+
+    @property
+    def stream(self) -> int:
+        return int(_lib.load().qsim_stream(self._h) or 0)
+
+    # -- stats
+    def stats(self) -> dict:
+        st = QsimStats()
+        check(_lib.load().qsim_get_stats(self._h, byref(st)))
+        return st.as_dict()
+
+    def reset_stats(self) -> None:
+        check(_lib.load().qsim_reset_stats(self._h))
+
+
+def run_qasm(path: str, device: int = 0, **sim_options) -> np.ndarray:
+    """QASM file in, amplitude vector out (the drop-in path of BASELINE.json's north_star)."""
+    c = Circuit.from_file(path)
+    with Simulator(c.num_qubits, device, **sim_options) as sim:
+        sim.run(c)
+        return sim.read()

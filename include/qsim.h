@@ -1,0 +1,160 @@
+/*
+ * qsim.h — C ABI of libqsim.so, the MI355X-native state-vector engine.
+ *
+ * Plain C: opaque handles, pointers and sizes only.  Every entry point names the reference interface
+ * it stands in for (file:line into RiccardoFiorentini/GPU_quantum_simulator).  The reference has no
+ * plugin/FFI layer: its drop-in surface is the CLI of quantum_simulator.c plus the three C functions
+ * declared at quantum_simulator.c:25-27, which live in qsim_legacy.h.  This header is the handle API
+ * those are built on — the state vector stays in HBM between gates.
+ *
+ * Conventions (quantum_simulator.c:83): qubit k is bit k of the amplitude index, q[0] = LSB.
+ * Amplitudes are fp64 complex, array-of-structs (re, im), 16 bytes each, exactly the memory layout of
+ * C99 `double _Complex` (quantum_simulator.c:35,168).  Matrices are row-major, (re, im) interleaved,
+ * and mean the standard U·v (NOT the transposed product of quantum_simulator.c:88-89; the legacy
+ * wrapper transposes for you).
+ *
+ * All functions return QSIM_OK (0) or a QSIM_ERR_* code; qsim_last_error() gives the message.
+ * The library never falls back to a CPU path: without a usable HIP device qsim_create fails.
+ */
+#ifndef QSIM_H
+#define QSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qsim_state qsim_state;     /* one state vector (or one shard of it) resident on one GPU */
+typedef struct qsim_circuit qsim_circuit; /* parsed gate list, host memory */
+
+enum {
+    QSIM_OK = 0,
+    QSIM_ERR_ARG = 1,    /* bad argument (NULL handle, qubit out of range, ...) */
+    QSIM_ERR_ALLOC = 2,  /* host or device allocation failed  ("Malloc error", quantum_simulator.c:170) */
+    QSIM_ERR_DEVICE = 3, /* HIP runtime error / no device */
+    QSIM_ERR_OPEN = 4,   /* cannot open circuit file          (quantum_simulator.c:128-131) */
+    QSIM_ERR_PARSE = 5   /* unknown token / malformed circuit (quantum_simulator.c:212-223) */
+};
+
+/* Gate kinds in a qsim_circuit. */
+enum { QSIM_GATE_U1 = 1, QSIM_GATE_CX = 2, QSIM_GATE_U2 = 3 };
+
+/* Options for qsim_set_option. */
+enum {
+    /* How adjacent gates are merged before launch:
+     *   0  one launch per gate                      (quantum_simulator_naive.cu:163-189)
+     *   1  per-qubit 2x2 accumulation, flush at CX  (quantum_simulator_preproces.cu:215-269)
+     *   2  pair clusters folded into one 4x4        (quantum_simulator_4x4.cu:327-501)
+     *   3  level 2 + cache-blocked passes: several clusters applied to an LDS-resident tile per
+     *      launch, op list read from device memory  (idea of quantum_simulator_preproces_constant.cu:169-178,
+     *      done with a full grid)                   [default]                                        */
+    QSIM_OPT_FUSE = 1,
+    QSIM_OPT_PROFILE = 2,      /* 1: bracket every launch with HIP events on the engine's stream */
+    QSIM_OPT_TILE_BITS = 3,    /* log2 amplitudes per LDS tile for level 3 (10..13, default 12) */
+    QSIM_OPT_TILE_LOW_BITS = 4,/* contiguous low index bits always inside a tile (default 7 -> 2 KiB runs) */
+    QSIM_OPT_MAX_PENDING = 5,  /* queued gates that force a flush (default 1<<16) */
+    QSIM_OPT_TILE_MAX_OPS = 6, /* upper bound on fused blocks per tile pass (default 24) */
+    QSIM_OPT_GRID_CAP = 7      /* 0: one workgroup per tile; >0: persistent grid of that many workgroups */
+};
+
+/* Kernel classes reported by qsim_get_stats. */
+enum {
+    QSIM_K_INIT = 0,
+    QSIM_K_GATE1 = 1,  /* dense 2x2, target bit >= 6: two coalesced streams            */
+    QSIM_K_GATE1_LO = 2,/* dense 2x2, target bit < 6: in-wave shuffle butterfly         */
+    QSIM_K_PHASE = 3,  /* diag(1, lambda): touches the bit=1 half only                 */
+    QSIM_K_CX = 4,     /* swap on the control=1 half                                   */
+    QSIM_K_GATE2 = 5,  /* dense 4x4 (any bit positions)                                */
+    QSIM_K_TILE = 6,   /* cache-blocked multi-op pass                                  */
+    QSIM_K_PACK = 7,   /* shard re-layout before a global<->local qubit exchange       */
+    QSIM_K_COUNT = 8
+};
+
+typedef struct {
+    uint64_t gates;                     /* gate statements accepted (pre-fusion)                     */
+    uint64_t launches;                  /* kernels launched                                          */
+    double algorithmic_bytes;           /* sum over launches of the bytes the pass must move         */
+    uint64_t k_launches[QSIM_K_COUNT];
+    double k_bytes[QSIM_K_COUNT];       /* algorithmic bytes per class                               */
+    double k_ms[QSIM_K_COUNT];          /* HIP-event time per class (QSIM_OPT_PROFILE=1), else 0     */
+} qsim_stats;
+
+/* ---- device / lifecycle -------------------------------------------------------------------------- */
+int qsim_device_count(void);
+const char *qsim_last_error(void);
+
+/* Allocates 2^num_q amplitudes on `device` and sets |0...0>.  Replaces the malloc + init loop of the
+ * `qubit` statement (quantum_simulator.c:168-177) and init_state_vector (quantum_simulator_naive.cu:64-70). */
+int qsim_create(qsim_state **out, int num_q, int device);
+/* Same, on caller-owned device memory of 16<<num_q bytes (e.g. a torch tensor's storage). */
+int qsim_create_external(qsim_state **out, int num_q, int device, void *device_amps);
+void qsim_destroy(qsim_state *s);
+int qsim_reset(qsim_state *s); /* back to |0...0>; drops queued gates */
+int qsim_num_qubits(const qsim_state *s);
+int qsim_set_option(qsim_state *s, int option, long value);
+long qsim_get_option(const qsim_state *s, int option);
+
+/* ---- gates: queued in program order, merged and launched at flush ---------------------------------- */
+/* execute_single_qubit_gate (quantum_simulator.c:81-92), kernel_gate (quantum_simulator_naive.cu:72-95).
+ * U: 4 complex, row-major, standard U·v. */
+int qsim_apply_1q(qsim_state *s, const double *U, int target);
+/* execute_cnot (quantum_simulator.c:94-106), kernel_cnot (quantum_simulator_naive.cu:97-122). */
+int qsim_apply_cx(qsim_state *s, int control, int target);
+/* kernel_gate_4 (quantum_simulator_4x4.cu:109-146): U is 16 complex, row/col index = (bit q_hi, bit q_lo). */
+int qsim_apply_2q(qsim_state *s, const double *U, int q_hi, int q_lo);
+int qsim_flush(qsim_state *s); /* schedule + launch everything queued; returns without waiting */
+int qsim_sync(qsim_state *s);  /* flush, then wait for the stream */
+
+/* ---- amplitudes in / out (the reference's final cudaMemcpy D2H, quantum_simulator_naive.cu:193-194) -- */
+int qsim_read(qsim_state *s, uint64_t first, uint64_t count, double *out_re_im);
+int qsim_write(qsim_state *s, uint64_t first, uint64_t count, const double *in_re_im);
+int qsim_norm2(qsim_state *s, double *out); /* sum |a|^2 computed on the device */
+void *qsim_device_ptr(qsim_state *s);        /* amplitude array in HBM */
+void *qsim_stream(qsim_state *s);            /* the hipStream_t every launch goes to */
+
+int qsim_get_stats(qsim_state *s, qsim_stats *out); /* waits for outstanding profile events */
+int qsim_reset_stats(qsim_state *s);
+
+/* ---- circuits: the tokenizer of compute_state_vector (quantum_simulator.c:115-254) ---------------- */
+/* Parses the OPENQASM-3 subset of quantum_simulator.c (two header statements, `qubit[n] q;` or
+ * `qubit q[n];`, gates cx x sx z s sdg t tdg rz(<number>) h, operands q[k] or $k).  A file whose first
+ * token is a number is read in the CUDA variants' `<num_qubit> <num_gates>` form
+ * (quantum_simulator_naive.cu:239-240). */
+int qsim_circuit_parse_file(const char *path, qsim_circuit **out);
+int qsim_circuit_parse_text(const char *text, size_t len, qsim_circuit **out);
+int qsim_circuit_create(int num_q, qsim_circuit **out);
+void qsim_circuit_free(qsim_circuit *c);
+int qsim_circuit_num_qubits(const qsim_circuit *c);
+long qsim_circuit_num_gates(const qsim_circuit *c);
+int qsim_circuit_append_1q(qsim_circuit *c, const double *U, int target);
+int qsim_circuit_append_cx(qsim_circuit *c, int control, int target);
+int qsim_circuit_append_2q(qsim_circuit *c, const double *U, int q_hi, int q_lo); /* q_hi > q_lo */
+/* kind: QSIM_GATE_*; q0 = target / control / q_hi, q1 = -1 / target / q_lo; U receives 8 (U1) or 32 (U2) doubles */
+int qsim_circuit_gate(const qsim_circuit *c, long index, int *kind, int *q0, int *q1, double *U);
+/* Text of the parse error (the reference prints "Unknown token: %s", quantum_simulator.c:213). */
+const char *qsim_circuit_error(void);
+/* Queues gates [first, first+count) of the circuit on the state (count < 0: to the end). */
+int qsim_run_circuit(qsim_state *s, const qsim_circuit *c, long first, long count);
+/* The gate table (quantum_simulator.c:184-211): name -> 2x2, standard orientation. Returns QSIM_GATE_U1,
+ * QSIM_GATE_CX for "cx", or 0 for an unknown token. */
+int qsim_gate_matrix(const char *token, double *U);
+
+/* ---- scheduling only (host code, no device): what a flush WOULD launch ----------------------------- */
+/* Runs the fusion scheduler on a circuit and reports launches and algorithmic bytes per kernel class
+ * for a state of num_q qubits at the given fuse level.  Used by tests and by the planner. */
+int qsim_plan_circuit(const qsim_circuit *c, int fuse, int tile_bits, int tile_low_bits, qsim_stats *out);
+/* Same scheduler, op by op: calls `cb` for every fused block in launch order with the pass it belongs to,
+ * the kernel class of that pass, the block kind (QSIM_GATE_U1 / _CX / _U2), its qubits and its matrix
+ * (8 or 32 doubles; NULL for CX).  Lets a CPU test replay the schedule with numpy and compare it with
+ * the unfused circuit. */
+typedef void (*qsim_sched_cb)(void *user, int pass, int kernel_class, int kind, int q0, int q1, const double *U,
+                              int gates_folded);
+int qsim_schedule_circuit(const qsim_circuit *c, int fuse, int tile_bits, int tile_low_bits, int tile_max_ops,
+                          qsim_sched_cb cb, void *user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QSIM_H */

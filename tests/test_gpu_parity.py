@@ -1,0 +1,297 @@
+"""Parity tests proper: the HIP path (through the C ABI of libqsim.so) against the oracle on the same
+inputs.  fp64 tolerance from BASELINE.json's north_star: 1e-10 absolute per amplitude (the kernels use
+FMA contraction and fused matrices, so results are not bit-identical to the reference's C arithmetic)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from gpu_quantum_simulator_amd import Circuit, Simulator, circuits, gate_matrix, run_qasm
+from gpu_quantum_simulator_amd import _lib
+from helpers import np_apply_1q, np_apply_2q, np_apply_cx, random_unitary
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10  # north_star: "amplitudes within 1e-10 abs for fp64"
+
+GOLDEN = ["entanglement", "grover_3_18", "rand_n3_all_lf", "rand_n5_all_crlf_physical", "rand_n8_all_suffix",
+          "rand_n9_clifford_t", "rand_n10_all", "rand_n12_all", "rand_n12_clifford_t_physical"]
+
+
+def _rand_state(n, seed):
+    rng = np.random.default_rng(seed)
+    s = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+    return (s / np.linalg.norm(s)).astype(np.complex128)
+
+
+@pytest.mark.parametrize("fuse", [0, 1, 2, 3])
+@pytest.mark.parametrize("name", GOLDEN)
+def test_golden_fixtures(golden_dir, name, fuse):
+    want = np.load(os.path.join(golden_dir, name + ".npy"), allow_pickle=False).view(np.complex128).reshape(-1)
+    got = run_qasm(os.path.join(golden_dir, name + ".qasm"), fuse=fuse)
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) < TOL
+
+
+@pytest.mark.parametrize("fuse", [0, 3])
+def test_grover_widened_to_18_qubits(golden_dir, fuse):
+    want = np.load(os.path.join(golden_dir, "grover_3_18_n18.first64.npy"), allow_pickle=False).view(np.complex128).reshape(-1)
+    got = run_qasm(os.path.join(golden_dir, "grover_3_18_n18.qasm"), fuse=fuse)
+    assert got.size == 1 << 18
+    assert np.max(np.abs(got[:64] - want)) < TOL and not got[64:].any()
+    assert int(np.argmax(np.abs(got))) in (3, 18)
+
+
+def test_dense_1q_every_target_bit(oracle):
+    """k_gate1_lo (q < 6, shuffle butterfly) and k_gate1_hi (q >= 6) with a NON-symmetric unitary, so the
+    orientation (standard U·v; the oracle applies the transpose of its argument) is pinned too."""
+    n = 13
+    rng = np.random.default_rng(1)
+    with Simulator(n, fuse=0) as sim:
+        for q in range(n):
+            U = random_unitary(2, rng)
+            s = _rand_state(n, 100 + q)
+            sim.write(s)
+            sim.apply_1q(U, q)
+            got = sim.read()
+            want = s.copy()
+            oracle.apply_1q(want, n, U.T, q)
+            assert np.max(np.abs(got - want)) < TOL, q
+        kinds = sim.stats()["kernels"]
+        assert kinds["gate1_lo"]["launches"] == 6 and kinds["gate1"]["launches"] == n - 6
+
+
+def test_diagonal_1q_every_target_bit(oracle):
+    n = 12
+    with Simulator(n, fuse=0) as sim:
+        for q in range(n):
+            for tok in ("t", "z", "rz(0.3)"):
+                U = gate_matrix(tok)
+                s = _rand_state(n, 200 + q)
+                sim.write(s)
+                sim.apply_1q(U, q)
+                got = sim.read()
+                want = s.copy()
+                oracle.apply_1q(want, n, U.T, q)
+                assert np.max(np.abs(got - want)) < TOL, (q, tok)
+            D = np.diag([np.exp(0.7j), np.exp(-0.2j)])  # d0 != 1: the full-sweep diagonal kernel
+            s = _rand_state(n, 300 + q)
+            sim.write(s)
+            sim.apply_1q(D, q)
+            assert np.max(np.abs(sim.read() - np_apply_1q(s, n, D, q))) < TOL
+        assert sim.stats()["kernels"]["phase"]["launches"] == 4 * n
+
+
+def test_cx_every_ordered_pair(oracle):
+    n = 11
+    with Simulator(n, fuse=0) as sim:
+        s = _rand_state(n, 7)
+        for c in range(n):
+            for t in range(n):
+                sim.write(s)
+                sim.apply_cx(c, t)
+                got = sim.read()
+                want = s.copy()
+                oracle.apply_cx(want, n, c, t)
+                assert np.array_equal(got, want), (c, t)  # pure data movement: bit-exact
+
+
+def test_dense_2q_every_pair():
+    """k_gate2_hh for lo >= 6, single-op tile passes otherwise."""
+    n = 12
+    rng = np.random.default_rng(3)
+    with Simulator(n, fuse=0) as sim:
+        s = _rand_state(n, 8)
+        for hi in range(1, n):
+            for lo in range(hi):
+                U = random_unitary(4, rng)
+                sim.write(s)
+                sim.apply_2q(U, hi, lo)
+                got = sim.read()
+                assert np.max(np.abs(got - np_apply_2q(s, n, U, hi, lo))) < TOL, (hi, lo)
+        k = sim.stats()["kernels"]
+        assert k["gate2"]["launches"] == 15 and k["tile"]["launches"] == 66 - 15
+
+
+@pytest.mark.parametrize("n,depth,seed,vocab,opts", [
+    (14, 400, 21, "all", {}),
+    (16, 600, 22, "clifford_t", {}),
+    (17, 500, 23, "all", {"tile_bits": 10, "tile_low_bits": 6}),
+    (18, 500, 24, "all", {"tile_bits": 13, "tile_low_bits": 7}),
+    (20, 300, 25, "all", {"tile_bits": 11, "tile_low_bits": 8, "tile_max_ops": 3}),
+    (20, 300, 26, "all", {"grid_cap": 64}),
+])
+def test_random_circuits_cache_blocked(oracle, tmp_path, n, depth, seed, vocab, opts):
+    path = circuits.random_circuit_file(str(tmp_path / "c.qasm"), n, depth, seed, vocab)
+    _, want, _, _ = oracle.run_qasm(path)
+    got = run_qasm(path, fuse=3, **opts)
+    assert np.max(np.abs(got - want)) < TOL
+
+
+@pytest.mark.parametrize("fuse", [0, 1, 2])
+def test_random_circuit_other_fusion_levels(oracle, tmp_path, fuse):
+    n = 17
+    path = circuits.random_circuit_file(str(tmp_path / "c.qasm"), n, 400, 31 + fuse, "all")
+    _, want, _, _ = oracle.run_qasm(path)
+    assert np.max(np.abs(run_qasm(path, fuse=fuse) - want)) < TOL
+
+
+def test_tiny_registers(oracle, tmp_path):
+    for n in (1, 2, 3, 5, 6, 7):
+        path = circuits.random_circuit_file(str(tmp_path / f"c{n}.qasm"), n, 60, 40 + n, "all")
+        _, want, _, _ = oracle.run_qasm(path)
+        for fuse in (0, 2, 3):
+            assert np.max(np.abs(run_qasm(path, fuse=fuse) - want)) < TOL, (n, fuse)
+
+
+def test_cx_same_qubit_and_flush_semantics():
+    with Simulator(4) as sim:
+        H = gate_matrix("h")
+        for q in range(4):
+            sim.apply_1q(H, q)
+        sim.apply_cx(2, 2)  # silent no-op in the reference (quantum_simulator.c:99)
+        a = sim.read()
+        assert np.allclose(a, 0.25, atol=1e-15)
+        assert sim.stats()["gates"] == 5
+        with pytest.raises(_lib.QsimError):
+            sim.apply_1q(H, 4)
+        with pytest.raises(_lib.QsimError):
+            sim.apply_cx(0, 9)
+
+
+def test_n26_against_truncated_oracle(oracle, tmp_path):
+    """1 GiB state (beyond the 256 MiB Infinity Cache): 24 gates on the CPU take a few seconds."""
+    n = 26
+    gates = circuits.random_gates(n, 24, 77, "all")
+    path = circuits.write_qasm(str(tmp_path / "c.qasm"), n, gates)
+    _, want, _, _ = oracle.run_qasm(path)
+    for fuse in (0, 3):
+        c = Circuit.from_file(path)
+        with Simulator(n, fuse=fuse) as sim:
+            sim.run(c)
+            got = sim.read()
+        assert np.max(np.abs(got - want)) < TOL, fuse
+
+
+def _inverse(gates):
+    inv = []
+    for g in reversed(gates):
+        if g[0] == "cx":
+            inv.append(g)
+        elif g[0] == "rz":
+            inv.append(("rz", -g[1], g[2]))
+        elif g[0] == "sx":
+            inv.extend([g, g, g])  # sx^4 = I
+        else:
+            inv.append(({"s": "sdg", "sdg": "s", "t": "tdg", "tdg": "t"}.get(g[0], g[0]), g[1]))
+    return inv
+
+
+@pytest.mark.parametrize("n,fuse,depth", [(28, 3, 300), (30, 3, 200), (30, 2, 60)])
+def test_full_size_round_trip(n, fuse, depth):
+    """BASELINE sizes, size-independent property: circuit followed by its inverse returns |0...0>,
+    and the norm is 1 in between."""
+    gates = circuits.random_gates(n, depth, 900 + n, "all")
+    fwd = Circuit.from_gates(n, gates)
+    bwd = Circuit.from_gates(n, _inverse(gates))
+    with Simulator(n, fuse=fuse) as sim:
+        sim.run(fwd)
+        assert abs(sim.norm2() - 1.0) < 1e-10
+        mid = sim.read(0, 4)
+        assert abs(mid[0]) < 0.999  # the state really moved
+        sim.run(bwd)
+        assert abs(sim.norm2() - 1.0) < 1e-10
+        head = sim.read(0, 1 << 12)
+        assert abs(head[0] - 1.0) < TOL and np.max(np.abs(head[1:])) < TOL
+        tail = sim.read((1 << n) - 4096, 4096)
+        assert np.max(np.abs(tail)) < TOL
+
+
+def test_linearity_at_n28():
+    """U(a|x> + b|y>) = aU|x> + bU|y> on sampled amplitudes."""
+    n = 27
+    gates = circuits.random_gates(n, 120, 555, "all")
+    c = Circuit.from_gates(n, gates)
+    outs = []
+    with Simulator(n) as sim:
+        for prep in ((), (("x", 3),), (("x", 20), ("x", 3))):
+            sim.reset()
+            for g in prep:
+                sim.apply_1q(gate_matrix(g[0]), g[1])
+            sim.run(c)
+            outs.append(sim.read(12345, 2048))
+        # superposition of basis states |8> and |2^20+8>: H on qubit 20 after X on 3
+        sim.reset()
+        sim.apply_1q(gate_matrix("x"), 3)
+        sim.apply_1q(gate_matrix("h"), 20)
+        sim.run(c)
+        mix = sim.read(12345, 2048)
+    want = (outs[1] + outs[2]) / np.sqrt(2.0)
+    assert np.max(np.abs(mix - want)) < TOL
+
+
+def test_cli_matches_reference_surface(oracle, golden_dir, tmp_path):
+    exe = _lib.CLI_PATH
+    dump = str(tmp_path / "amps.bin")
+    env = dict(os.environ, QSIM_DUMP=dump)
+    p = subprocess.run([exe, os.path.join(golden_dir, "grover_3_18.qasm"), "10"], capture_output=True, text=True, env=env)
+    assert p.returncode == 0
+    lines = p.stdout.splitlines()
+    assert len(lines) == 1 and float(lines[0]) >= 0 and "." in lines[0]  # exactly one "%lf" line
+    want = np.load(os.path.join(golden_dir, "grover_3_18.npy")).view(np.complex128).reshape(-1)
+    got = np.fromfile(dump, dtype=np.complex128)
+    assert np.max(np.abs(got - want)) < TOL
+    # error surface
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode == 1 and p.stdout.startswith("QUANTUM CIRCUIT SIMULATOR\nUsage: ")
+    p = subprocess.run([exe, "/no/such/file.qasm", "1"], capture_output=True, text=True)
+    assert p.returncode == 1 and p.stdout == "ERROR: cannot open circuit file\n"
+    bad = tmp_path / "bad.qasm"
+    bad.write_text('OPENQASM 3.0;\ninclude "stdgates.inc";\nqubit[2] q;\nfoo q[0];\n')
+    p = subprocess.run([exe, str(bad), "1"], capture_output=True, text=True)
+    assert p.returncode == 1 and p.stdout.startswith("Unknown token: foo\nInput format: ")
+    assert p.stdout.endswith("ERROR while parsing quantum circuit\n")
+
+
+def test_legacy_entry_points(oracle, golden_dir, capfd):
+    lib = _lib.load()
+    lib.compute_state_vector.restype = ctypes.c_void_p
+    lib.compute_state_vector.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    n = ctypes.c_int(0)
+    p = lib.compute_state_vector(os.path.join(golden_dir, "rand_n10_all.qasm").encode(), ctypes.byref(n))
+    assert p and n.value == 10
+    got = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_double)), shape=(2 << 10,)).copy().view(np.complex128)
+    ctypes.CDLL(None).free(ctypes.c_void_p(p))
+    want = np.load(os.path.join(golden_dir, "rand_n10_all.npy")).view(np.complex128).reshape(-1)
+    assert np.max(np.abs(got - want)) < TOL
+
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.execute_single_qubit_gate.argtypes = [dp, ctypes.c_int, dp, ctypes.c_int]
+    lib.execute_cnot.argtypes = [dp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    rng = np.random.default_rng(11)
+    U = (rng.standard_normal(4) + 1j * rng.standard_normal(4)).astype(np.complex128)  # arbitrary, not symmetric
+    a = _rand_state(9, 12)
+    b = a.copy()
+    for q in (0, 5, 8):
+        lib.execute_single_qubit_gate(a.view(np.float64).ctypes.data_as(dp), 9, U.view(np.float64).ctypes.data_as(dp), q)
+        oracle.apply_1q(b, 9, U, q)  # same argument, same (transposed) meaning as quantum_simulator.c:88-89
+        lib.execute_cnot(a.view(np.float64).ctypes.data_as(dp), 9, q, (q + 4) % 9)
+        oracle.apply_cx(b, 9, q, (q + 4) % 9)
+    assert np.max(np.abs(a - b)) < 1e-9 * max(1.0, np.max(np.abs(b)))
+
+
+def test_profile_stats_and_bytes():
+    n = 22
+    with Simulator(n, fuse=0, profile=True) as sim:
+        H = gate_matrix("h")
+        sim.reset_stats()
+        for _ in range(5):
+            sim.apply_1q(H, 10)
+        sim.apply_cx(3, 15)
+        sim.sync()
+        st = sim.stats()
+    S = 16.0 * (1 << n)
+    assert st["kernels"]["gate1"]["launches"] == 5 and st["kernels"]["gate1"]["bytes"] == 5 * 2 * S
+    assert st["kernels"]["cx"]["bytes"] == S
+    assert st["kernels"]["gate1"]["ms"] > 0 and st["kernels"]["cx"]["ms"] > 0

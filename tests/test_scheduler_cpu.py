@@ -1,0 +1,181 @@
+"""Host logic on the CPU: tokenizer, gate table and the fusion scheduler of libqsim.so (no device calls).
+
+The scheduler's output (fused blocks in launch order) is replayed with numpy and compared with the
+oracle running the unfused circuit — this pins the fusion algebra and the reordering rules
+ without a GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from gpu_quantum_simulator_amd import Circuit, circuits, gate_matrix
+from gpu_quantum_simulator_amd import _lib
+from helpers import np_apply_1q, np_apply_2q, np_apply_cx, random_unitary, replay_schedule
+
+TOL = 1e-12
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    for name in list(_lib.SIGNATURES) + list(_lib.LEGACY_SYMBOLS):
+        assert hasattr(lib, name), name
+
+
+def test_header_and_binding_agree():
+    """Every function prototype in include/qsim.h has a ctypes signature and vice versa."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "qsim.h")).read()
+    declared = set(re.findall(r"\b(qsim_[a-z0-9_]+)\s*\(", text)) - {"qsim_sched_cb"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    legacy = open(os.path.join(root, "include", "qsim_legacy.h")).read()
+    for name in _lib.LEGACY_SYMBOLS:
+        assert re.search(rf"\b{name}\s*\(", legacy)
+
+
+def test_no_device_means_loud_failure_not_fallback():
+    lib = _lib.load()
+    if lib.qsim_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from gpu_quantum_simulator_amd import Simulator
+    with pytest.raises(_lib.QsimError, match="no HIP device"):
+        Simulator(3)
+
+
+def test_gate_table_equals_oracle(oracle):
+    for tok in ["x", "sx", "z", "s", "sdg", "t", "tdg", "h", "rz(0.25)", "rz(-3.0000000001)", "rz(1e-3)"]:
+        kind, want = oracle.gate_matrix(tok)
+        got = gate_matrix(tok)
+        assert kind == 3 and got is not None
+        # the product stores U, the oracle stores the reference's table; all are symmetric
+        assert got.tobytes() == want.tobytes(), tok
+    assert gate_matrix("cx") is None and gate_matrix("ccx") is None and gate_matrix("rz(") is None
+
+
+@pytest.mark.parametrize("name", ["entanglement", "grover_3_18", "rand_n5_all_crlf_physical", "rand_n8_all_suffix",
+                                  "rand_n9_clifford_t", "rand_n12_clifford_t_physical"])
+def test_tokenizer_matches_generator_and_oracle(oracle, golden_dir, name):
+    c = Circuit.from_file(os.path.join(golden_dir, name + ".qasm"))
+    n, amps, _, gates = oracle.run_qasm(os.path.join(golden_dir, name + ".qasm"))
+    assert c.num_qubits == n and len(c) == gates
+    # replaying the parsed gate list with the oracle's kernels reproduces the oracle's own run bit for bit
+    s = oracle.zero_state(n)
+    for i in range(len(c)):
+        g = c.gate(i)
+        if g[0] == "cx":
+            oracle.apply_cx(s, n, g[1], g[2])
+        else:
+            oracle.apply_1q(s, n, g[2].T, g[1])  # the oracle applies the transpose of its argument
+    assert s.tobytes() == amps.tobytes()
+
+
+def test_counted_header_form():
+    text = "3 4\nh q[0];\ncx q[0], q[2];\nrz(0.5) $1;\nt q[2];\nx q[1];\n"  # 5th statement beyond the count
+    c = Circuit.from_text(text)
+    assert c.num_qubits == 3 and len(c) == 4
+    assert c.gate(1) == ("cx", 0, 2) and c.gate(2)[1] == 1
+
+
+def test_parse_errors():
+    hdr = 'OPENQASM 3.0;\ninclude "stdgates.inc";\n'
+    with pytest.raises(_lib.QsimError, match="Unknown token: foo") as e:
+        Circuit.from_text(hdr + "qubit[2] q;\nfoo q[0];\n")
+    assert e.value.code == _lib.ERR_PARSE
+    with pytest.raises(_lib.QsimError, match="out of range"):
+        Circuit.from_text(hdr + "qubit[2] q;\nh q[2];\n")
+    with pytest.raises(_lib.QsimError, match="before the qubit statement"):
+        Circuit.from_text(hdr + "h q[0];\n")
+    with pytest.raises(_lib.QsimError) as e:
+        Circuit.from_file("/nonexistent/file.qasm")
+    assert e.value.code == _lib.ERR_OPEN
+    assert len(Circuit.from_text(hdr + "qubit[2] q;\n")) == 0  # empty circuit is fine
+
+
+@pytest.mark.parametrize("fuse", [0, 1, 2, 3])
+@pytest.mark.parametrize("n,depth,seed,vocab", [(3, 80, 1, "all"), (6, 300, 2, "all"), (9, 400, 3, "clifford_t"),
+                                                (11, 600, 4, "all")])
+def test_schedule_replay_equals_oracle(oracle, tmp_path, fuse, n, depth, seed, vocab):
+    gates = circuits.random_gates(n, depth, seed, vocab)
+    path = circuits.write_qasm(str(tmp_path / "c.qasm"), n, gates)
+    _, want, _, _ = oracle.run_qasm(path)
+    c = Circuit.from_file(path)
+    # small tiles so that grouping, high-bit selection and blocking all get exercised at n <= 11
+    sched = c.schedule(fuse=fuse, tile_bits=8, tile_low_bits=4, tile_max_ops=6)
+    got = replay_schedule(n, sched)
+    assert np.max(np.abs(got - want)) < TOL
+    assert sum(s[6] for s in sched) <= depth  # folded gate counts never exceed the input
+
+
+def test_schedule_counts_every_gate_once_at_level0(tmp_path):
+    gates = circuits.random_gates(7, 200, 9, "all")
+    c = Circuit.from_gates(7, gates)
+    sched = c.schedule(fuse=0)
+    assert len(sched) == 200 and all(s[6] == 1 for s in sched)
+    assert [s[2] for s in sched] == ["cx" if g[0] == "cx" else "u1" for g in gates]
+
+
+def test_level2_pairs_follow_reference_example():
+    """h q0; cx q0,q1 folds into ONE 4x4 = CX·(I⊗H) (the case A of quantum_simulator_4x4.cu:336-349)."""
+    c = Circuit.from_text('OPENQASM 3.0;\ninclude "stdgates.inc";\nqubit q[2];\nh q[0];\ncx q[0], q[1];\n')
+    sched = c.schedule(fuse=2)
+    assert len(sched) == 1 and sched[0][2] == "u2" and sched[0][3:5] == (1, 0) and sched[0][6] == 2
+    H = gate_matrix("h")
+    CX_ctrl_lo = np.array([[1, 0, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0], [0, 1, 0, 0]], dtype=complex)
+    assert np.allclose(sched[0][5], CX_ctrl_lo @ np.kron(np.eye(2), H), atol=0, rtol=0)
+
+
+def test_exact_identity_is_dropped_but_near_identity_is_kept():
+    c = Circuit.empty(3)
+    X = gate_matrix("x")
+    c.append_1q(X, 1)
+    c.append_1q(X, 1)  # X·X = I exactly
+    eps = np.array([[1, 0], [0, np.exp(1e-4j)]])  # would pass the reference's 1e-3 isIdentity test (B9)
+    c.append_1q(eps, 2)
+    sched = c.schedule(fuse=2)
+    assert len(sched) == 1 and sched[0][3] == 2 and np.array_equal(sched[0][5], eps)
+
+
+def test_generic_two_qubit_gates_and_blocking(oracle):
+    rng = np.random.default_rng(7)
+    n = 10
+    c = Circuit.empty(n)
+    ref = np.zeros(1 << n, dtype=np.complex128)
+    ref[0] = 1
+    for _ in range(120):
+        r = rng.integers(3)
+        if r == 0:
+            q = int(rng.integers(n)); U = random_unitary(2, rng)
+            c.append_1q(U, q); ref = np_apply_1q(ref, n, U, q)
+        elif r == 1:
+            a, b = (int(x) for x in rng.choice(n, 2, replace=False))
+            c.append_cx(a, b); ref = np_apply_cx(ref, n, a, b)
+        else:
+            lo, hi = sorted(int(x) for x in rng.choice(n, 2, replace=False))
+            U = random_unitary(4, rng)
+            c.append_2q(U, hi, lo); ref = np_apply_2q(ref, n, U, hi, lo)
+    for fuse in (0, 1, 2, 3):
+        got = replay_schedule(n, c.schedule(fuse=fuse, tile_bits=8, tile_low_bits=5, tile_max_ops=4))
+        assert np.max(np.abs(got - ref)) < TOL, fuse
+
+
+def test_plan_reports_fewer_passes_with_more_fusion():
+    gates = circuits.random_gates(30, 1000, 20240117 + 30, "all")
+    c = Circuit.from_gates(30, gates)
+    launches = [c.plan(fuse=f)["launches"] for f in (0, 1, 2, 3)]
+    assert launches[0] == 1000 and launches[0] > launches[1] > launches[2] > launches[3]
+    p3 = c.plan(fuse=3)
+    assert p3["gates"] == 1000 and p3["algorithmic_bytes"] == p3["launches"] * 32.0 * 2 ** 30
+
+
+def test_tile_passes_respect_geometry_limits():
+    gates = circuits.random_gates(20, 600, 5, "all")
+    c = Circuit.from_gates(20, gates)
+    sched = c.schedule(fuse=3, tile_bits=10, tile_low_bits=6, tile_max_ops=5)
+    by_pass = {}
+    for s in sched:
+        by_pass.setdefault(s[0], []).append(s)
+    for ops in by_pass.values():
+        assert len(ops) <= 5
+        if ops[0][1] == "tile":
+            high = {q for o in ops for q in (o[3], o[4]) if q >= 6}
+            assert len(high) <= 4

@@ -53,6 +53,26 @@ def parse_args():
     return ap.parse_args()
 
 
+KERNEL_SYMBOL = {"tile": "qsim::k_tile<256>", "gate1": "qsim::k_gate1_hi<4, false>", "gate1_lo": "qsim::k_gate1_lo<4, false>",
+                 "gate2": "qsim::k_gate2_hh<2, false>"}
+
+
+def pmc_traffic(kernel_class, is_default_workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this same
+    command (profiles/rNN/bench_n30_pmc_summary.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes).
+    Counters cannot be read from inside the process, so this is null for any other workload."""
+    if not is_default_workload:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_n30_pmc_summary.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        summary = json.load(f)
+    entry = summary.get("kernels", {}).get(KERNEL_SYMBOL.get(kernel_class, ""), None)
+    return entry["hbm_traffic_bytes_per_launch"] if entry else None
+
+
 def cpu_baseline(n, gates, budget_s):
     """The reference's hot loops on this host's cores (1 thread), bounded sample of the same circuit."""
     import ctypes
@@ -173,7 +193,9 @@ def main():
         if dom and kernels[dom]["ms"] > 0:
             achieved = kernels[dom]["bytes"] / (kernels[dom]["ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBPS,
+                    "traffic": pmc_traffic(dom, args.probe is None and n == 30 and args.depth == 1000 and fuse == 3
+                                           and args.gpus == 1 and not opts and args.vocabulary == "all"),
                     "launches": kernels[dom]["launches"],
                     "avg_launch_ms": kernels[dom]["ms"] / kernels[dom]["launches"],
                     "algorithmic_bytes_per_launch": kernels[dom]["bytes"] / kernels[dom]["launches"]}

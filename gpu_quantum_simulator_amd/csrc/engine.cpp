@@ -61,7 +61,7 @@ struct qsim_state {
     double2 *amps = nullptr;
     bool owns = false;
     // options
-    int fuse = 3, profile = 0, tile_bits = 12, tile_low_bits = 7, tile_max_ops = 24, grid_cap = 0;
+    int fuse = 3, profile = 0, tile_bits = 11, tile_low_bits = 6, tile_max_ops = 24, grid_cap = 0;
     long max_pending = 1L << 16;
     // queue
     std::vector<QueuedGate> queue;

@@ -44,8 +44,8 @@ struct Pass {
 struct SchedConfig {
     int n = 0;
     int fuse = 3;
-    int tile_bits = 12;
-    int tile_low_bits = 7;
+    int tile_bits = 11;
+    int tile_low_bits = 6;
     int tile_max_ops = 24;
     int window = 4096; // clusters scanned ahead when grouping a pass
 };

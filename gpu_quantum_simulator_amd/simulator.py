@@ -101,12 +101,12 @@ class Circuit:
             return ("cx", q0.value, q1.value)
         return ("u2", q0.value, q1.value, u.view(np.complex128).reshape(4, 4).copy())
 
-    def plan(self, fuse: int = 3, tile_bits: int = 12, tile_low_bits: int = 7) -> dict:
+    def plan(self, fuse: int = 3, tile_bits: int = 11, tile_low_bits: int = 6) -> dict:
         st = QsimStats()
         check(_lib.load().qsim_plan_circuit(self._h, fuse, tile_bits, tile_low_bits, byref(st)))
         return st.as_dict()
 
-    def schedule(self, fuse: int = 3, tile_bits: int = 12, tile_low_bits: int = 7, tile_max_ops: int = 24) -> list:
+    def schedule(self, fuse: int = 3, tile_bits: int = 11, tile_low_bits: int = 6, tile_max_ops: int = 24) -> list:
         """Fused blocks in launch order: (pass, kernel_class, kind, q0, q1, matrix|None, gates_folded)."""
         out = []
 

@@ -52,8 +52,8 @@ enum {
      *      done with a full grid)                   [default]                                        */
     QSIM_OPT_FUSE = 1,
     QSIM_OPT_PROFILE = 2,      /* 1: bracket every launch with HIP events on the engine's stream */
-    QSIM_OPT_TILE_BITS = 3,    /* log2 amplitudes per LDS tile for level 3 (10..13, default 12) */
-    QSIM_OPT_TILE_LOW_BITS = 4,/* contiguous low index bits always inside a tile (default 7 -> 2 KiB runs) */
+    QSIM_OPT_TILE_BITS = 3,    /* log2 amplitudes per LDS tile for level 3 (8..13, default 11) */
+    QSIM_OPT_TILE_LOW_BITS = 4,/* contiguous low index bits always inside a tile (default 6 -> 1 KiB runs) */
     QSIM_OPT_MAX_PENDING = 5,  /* queued gates that force a flush (default 1<<16) */
     QSIM_OPT_TILE_MAX_OPS = 6, /* upper bound on fused blocks per tile pass (default 24) */
     QSIM_OPT_GRID_CAP = 7      /* 0: one workgroup per tile; >0: persistent grid of that many workgroups */

@@ -52,6 +52,8 @@ SIGNATURES = {
     "qsim_norm2": (c_int, [c_void_p, _DP]),
     "qsim_device_ptr": (c_void_p, [c_void_p]),
     "qsim_stream": (c_void_p, [c_void_p]),
+    "qsim_pack_bits": (c_int, [c_void_p, POINTER(c_int), c_int, c_void_p]),
+    "qsim_scale": (c_int, [c_void_p, c_double, c_double]),
     "qsim_get_stats": (c_int, [c_void_p, POINTER(QsimStats)]),
     "qsim_reset_stats": (c_int, [c_void_p]),
     "qsim_circuit_parse_file": (c_int, [c_char_p, POINTER(c_void_p)]),

@@ -456,6 +456,33 @@ extern "C" int qsim_norm2(qsim_state *s, double *out) {
     return QSIM_OK;
 }
 
+extern "C" int qsim_pack_bits(qsim_state *s, const int *bits, int nbits, void *dst) {
+    if (!s || !bits || !dst) return fail(QSIM_ERR_ARG, "NULL argument");
+    if (nbits < 1 || nbits > 8 || nbits > s->n) return fail(QSIM_ERR_ARG, "pack: %d bits unsupported", nbits);
+    for (int j = 0; j < nbits; j++)
+        if (bits[j] < 0 || bits[j] >= s->n || (j && bits[j] <= bits[j - 1]))
+            return fail(QSIM_ERR_ARG, "pack: bit positions must be ascending and inside the shard");
+    if (dst == (void *)s->amps) return fail(QSIM_ERR_ARG, "pack: dst must not alias the state");
+    const int rc = qsim_flush(s);
+    if (rc) return rc;
+    LaunchCfg cfg{s->stream, s->grid_cap};
+    hipError_t e;
+    {
+        LaunchScope scope(s, QSIM_K_PACK);
+        e = launch_pack(cfg, s->amps, (double2 *)dst, s->n, bits, nbits);
+    }
+    if (e != hipSuccess) return fail(QSIM_ERR_DEVICE, "pack launch failed: %s", hipGetErrorString(e));
+    account(s, QSIM_K_PACK, 32.0 * (double)(1ULL << s->n));
+    return QSIM_OK;
+}
+
+extern "C" int qsim_scale(qsim_state *s, double re, double im) {
+    if (!s) return fail(QSIM_ERR_ARG, "NULL state");
+    if (s->n < 1) return fail(QSIM_ERR_ARG, "scale needs at least one local qubit");
+    const double U[8] = {re, im, 0, 0, 0, 0, re, im}; // diag(z, z) on local qubit 0: folds into the next fused block
+    return qsim_apply_1q(s, U, 0);
+}
+
 extern "C" int qsim_get_stats(qsim_state *s, qsim_stats *out) {
     if (!s || !out) return fail(QSIM_ERR_ARG, "NULL argument");
     const int rc = resolve_events(s);

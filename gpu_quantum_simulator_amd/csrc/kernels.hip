@@ -398,26 +398,55 @@ __global__ __launch_bounds__(TPB) void k_norm2(const amp_t *__restrict__ v, uint
 // Shard re-layout ahead of a global<->local qubit exchange: gathers so that the p selected index bits
 // become the top p bits (the destination block id) while the other bits keep their order.  Writes are
 // fully coalesced; reads come in runs of 2^bits[0] amplitudes.
-// Selected bits arrive as a mask; block bit j goes to the j-th lowest set bit.
+// Scatter form: consecutive lanes READ consecutive amplitudes (always fully coalesced); a wave's 64 stores
+// fall into 2^(selected bits below 6) contiguous segments, i.e. >= 128 B pieces for up to three selected
+// bits wherever they are.  (The gather form would read 16/32-B fragments when bit 0 or 1 is selected and
+// fetch those sectors once per destination block.)
+// dst = (pext(src, sel) << rest_bits) | pext(src, keep).  PEXT over disjoint bit ranges splits, so the part
+// that depends on the work tile is wave-uniform scalar work and the part that depends on the lane is
+// computed once per thread, outside the tile loop.
+__device__ __forceinline__ uint64_t extract(uint64_t x, uint64_t mask) { // software PEXT
+    uint64_t out = 0;
+    int k = 0;
+    while (mask) {
+        const uint64_t low = mask & (0 - mask);
+        if (x & low) out |= 1ULL << k;
+        k++;
+        mask &= mask - 1;
+    }
+    return out;
+}
+
 template <int IPT>
 __global__ __launch_bounds__(TPB) void k_pack(const amp_t *__restrict__ in, amp_t *__restrict__ out, uint64_t N, int n,
                                               int p, uint64_t sel_mask, uint64_t ntiles) {
+    constexpr int SB = 10; // log2(TPB * IPT): index bits owned by the position inside a work tile
+    static_assert(TPB * IPT == (1 << SB), "tile split");
     const int rest_bits = n - p;
-    const uint64_t rest_mask = (1ULL << rest_bits) - 1ULL;
     const uint64_t nmask = n >= 64 ? ~0ULL : ((1ULL << n) - 1ULL);
     const uint64_t keep_mask = nmask & ~sel_mask;
+    const uint64_t lo = (1ULL << SB) - 1ULL;
+    const int pc_keep_lo = __popcll(keep_mask & lo), pc_sel_lo = __popcll(sel_mask & lo);
+    uint64_t add[IPT];
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+        const uint64_t e = (uint64_t)k * TPB + threadIdx.x;
+        add[k] = (extract(e, sel_mask & lo) << rest_bits) | extract(e, keep_mask & lo);
+    }
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint64_t d0 = tile * (uint64_t)(TPB * IPT) + threadIdx.x;
+        const uint64_t base = ((extract(tile, sel_mask >> SB) << pc_sel_lo) << rest_bits) |
+                              (extract(tile, keep_mask >> SB) << pc_keep_lo); // wave-uniform
+        const uint64_t s0 = (tile << SB) + threadIdx.x;
         amp_t a[IPT];
 #pragma unroll
         for (int k = 0; k < IPT; k++) {
-            const uint64_t d = d0 + (uint64_t)k * TPB;
-            a[k] = d < N ? in[deposit(d & rest_mask, keep_mask) | deposit(d >> rest_bits, sel_mask)] : amp_t{0.0, 0.0};
+            const uint64_t sidx = s0 + (uint64_t)k * TPB;
+            a[k] = sidx < N ? in[sidx] : amp_t{0.0, 0.0};
         }
 #pragma unroll
         for (int k = 0; k < IPT; k++) {
-            const uint64_t d = d0 + (uint64_t)k * TPB;
-            if (d < N) out[d] = a[k];
+            const uint64_t sidx = s0 + (uint64_t)k * TPB;
+            if (sidx < N) out[base | add[k]] = a[k];
         }
     }
 }
@@ -525,8 +554,9 @@ hipError_t launch_pack(const LaunchCfg &cfg, const double2 *in, double2 *out, in
     for (int j = 0; j < p; j++) sel |= 1ULL << bits[j];
     const uint64_t N = 1ULL << n;
     const uint64_t nt = ceil_div(N, (uint64_t)TPB * 4);
-    hipLaunchKernelGGL(k_pack<4>, dim3(grid_for(cfg, nt)), dim3(TPB), 0, cfg.stream, (const amp_t *)in, (amp_t *)out, N, n, p,
-                       sel, nt);
+    unsigned grid = grid_for(cfg, nt);
+    if (grid > 8192) grid = 8192; // persistent: the per-thread PEXT above is paid once per 2^10 * (nt / grid) amplitudes
+    hipLaunchKernelGGL(k_pack<4>, dim3(grid), dim3(TPB), 0, cfg.stream, (const amp_t *)in, (amp_t *)out, N, n, p, sel, nt);
     return hipGetLastError();
 }
 

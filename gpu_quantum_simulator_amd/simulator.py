@@ -197,6 +197,14 @@ class Simulator:
     def flush(self) -> None:
         check(_lib.load().qsim_flush(self._h))
 
+    def pack_bits(self, bits: Sequence[int], dst_ptr: int) -> None:
+        """Shard re-layout ahead of a global<->local qubit exchange (qsim_pack_bits)."""
+        arr = (c_int * len(bits))(*bits)
+        check(_lib.load().qsim_pack_bits(self._h, arr, len(bits), c_void_p(dst_ptr)))
+
+    def scale(self, z: complex) -> None:
+        check(_lib.load().qsim_scale(self._h, float(z.real), float(z.imag)))
+
     def sync(self) -> None:
         check(_lib.load().qsim_sync(self._h))
 

@@ -114,6 +114,18 @@ int qsim_norm2(qsim_state *s, double *out); /* sum |a|^2 computed on the device 
 void *qsim_device_ptr(qsim_state *s);        /* amplitude array in HBM */
 void *qsim_stream(qsim_state *s);            /* the hipStream_t every launch goes to */
 
+/* ---- sharded states (new: the reference is single-device) --------------------------------
+ * A qsim_state may hold one contiguous shard of a larger register: the caller (one process per GPU)
+ * keeps the top log2(P) index bits as the rank id and owns the logical->physical qubit map.
+ * qsim_pack_bits re-lays the shard out ahead of a global<->local qubit exchange:
+ *     dst[(block << (n-k)) | rest] = amps[src],  block = the k bits of src at positions bits[0..k)
+ *                                                (ascending), rest = the other n-k bits in order,
+ * so block b is the contiguous piece rank-group member b must receive (RCCL send/recv or all-to-all of
+ * 16<<(n-k) byte blocks over xGMI).  dst is caller-owned device memory of 16<<n bytes. */
+int qsim_pack_bits(qsim_state *s, const int *bits, int nbits, void *dst_device);
+/* Multiplies every amplitude of the shard by (re, im): a diagonal gate on a global qubit is a per-rank scalar. */
+int qsim_scale(qsim_state *s, double re, double im);
+
 int qsim_get_stats(qsim_state *s, qsim_stats *out); /* waits for outstanding profile events */
 int qsim_reset_stats(qsim_state *s);
 

@@ -1,0 +1,128 @@
+"""The sharded path without GPUs: planner + logical->physical map + pack layout + exchange pattern.
+
+(1) VirtualCluster with CPU shards (oracle loops) for P = 2, 4, 8 must equal the oracle on the whole
+    register.  (2) The same through torch.distributed with the gloo backend, world_size 2 and 4, one
+    process per rank — the code path bench.py takes with nccl on real GPUs."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gpu_quantum_simulator_amd import circuits, gate_matrix
+from gpu_quantum_simulator_amd.distributed import (ShardPlan, ShardedSimulator, VirtualCluster, normalize_gates,
+                                                   logical_from_physical, peers_of, physical_index)
+from cpu_shard import CpuShard
+
+TOL = 1e-12
+
+
+def _oracle_state(oracle, tmp_path, n, gates):
+    path = circuits.write_qasm(str(tmp_path / f"c{n}.qasm"), n, gates)
+    return oracle.run_qasm(path)[1]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("n,depth,seed,vocab", [(6, 150, 1, "all"), (9, 400, 2, "all"), (11, 500, 3, "clifford_t")])
+def test_virtual_cluster_equals_oracle(oracle, tmp_path, world, n, depth, seed, vocab):
+    gates = circuits.random_gates(n, depth, seed, vocab)
+    want = _oracle_state(oracle, tmp_path, n, gates)
+    vc = VirtualCluster(n, world, gates, shard_factory=CpuShard)
+    vc.run()
+    got = vc.gather_logical()
+    assert np.max(np.abs(got - want)) < TOL
+    assert vc.plans[0].exchanges >= 1  # these circuits cannot avoid communication
+
+
+def test_plan_is_identical_across_ranks_and_counts_fraction():
+    n, p = 12, 3
+    gates = normalize_gates(circuits.random_gates(n, 600, 5, "all"), gate_matrix)
+    plans = [ShardPlan(n, p, gates, r) for r in range(8)]
+    shape = [(s[0],) + (s[1:] if s[0] == "exchange" else ()) for s in plans[0].steps]
+    for pl in plans[1:]:
+        assert [(s[0],) + (s[1:] if s[0] == "exchange" else ()) for s in pl.steps] == shape
+        assert pl.final_pos == plans[0].final_pos
+    assert sorted(plans[0].final_pos) == list(range(n))
+    for s in plans[0].steps:
+        if s[0] == "exchange":
+            J, L = s[1], s[2]
+            assert len(J) == len(L) and list(J) == sorted(J) and list(L) == sorted(L)
+            assert all(0 <= j < p for j in J) and all(0 <= l < n - p for l in L)
+
+
+def test_communication_free_gates_stay_local():
+    """Diagonal gates and controls on global qubits never trigger an exchange."""
+    n, p = 8, 2
+    gates = [("h", q) for q in range(6)] + [("t", 7), ("rz", 0.3, 6), ("cx", 7, 2), ("cx", 6, 0), ("z", 7), ("s", 6)]
+    norm = normalize_gates(gates, gate_matrix)
+    pl = ShardPlan(n, p, norm, rank=3, lookahead_free_start=False)
+    assert pl.exchanges == 0 and [s[0] for s in pl.steps] == ["local"]
+    kinds = [op[0] for op in pl.steps[0][1]]
+    assert kinds.count("scale") == 4 and kinds.count("u1") == 6 + 2  # rank 3 has both control bits set
+    pl0 = ShardPlan(n, p, norm, rank=0, lookahead_free_start=False)
+    assert [op[0] for op in pl0.steps[0][1]].count("u1") == 6  # controls clear, all scalars are 1
+
+
+def test_free_initial_placement_avoids_first_exchange():
+    n, p = 8, 2
+    gates = [("h", 7), ("h", 6), ("cx", 7, 6)] + [("t", 0), ("z", 1)]
+    norm = normalize_gates(gates, gate_matrix)
+    assert ShardPlan(n, p, norm, 0).exchanges == 0
+    assert ShardPlan(n, p, norm, 0, lookahead_free_start=False).exchanges == 1
+
+
+def test_peers_and_index_helpers():
+    mine, members = peers_of(0b101, [0, 2])
+    assert mine == 0b11 and members == [0b000, 0b001, 0b100, 0b101]
+    pos = [2, 0, 1]
+    assert physical_index(0b001, pos) == 0b100
+    phys = np.arange(8)
+    assert list(logical_from_physical(phys, pos)) == [physical_index(x, pos) for x in range(8)]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, gates, want, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sim = ShardedSimulator(n, gates, shard_factory=CpuShard)
+        for _ in range(2):  # a second step must start from a clean state and the identity map
+            sim.run_step()
+        norm = sim.norm2()
+        amp5 = sim.amplitude(5)
+        shards = [torch.zeros_like(sim.shard.state) for _ in range(world)]
+        dist.all_gather(shards, sim.shard.state)
+        phys = torch.cat(shards).numpy().reshape(-1).view(np.complex128)
+        got = logical_from_physical(phys, sim.plan.final_pos)
+        err = float(np.max(np.abs(got - want)))
+        q.put((rank, err, norm, abs(amp5 - want[5]), sim.plan.exchanges, sim.exchange_bytes))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_ranks_equal_oracle(oracle, tmp_path, world):
+    n = 10
+    gates = circuits.random_gates(n, 300, 40 + world, "all")
+    want = _oracle_state(oracle, tmp_path, n, gates)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, gates, want, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, norm, aerr, exchanges, xbytes in results:
+        assert err < TOL and abs(norm - 1.0) < 1e-12 and aerr < TOL
+        assert exchanges >= 1 and xbytes > 0

@@ -212,6 +212,13 @@ def main():
             "norm2": norm2,
             "roofline": roof,
         }
+        if world > 1:
+            xs = sim.exchange_seconds / args.steps
+            xb = sim.exchange_bytes / args.steps
+            out["exchange"] = {"per_step": sim.plan.exchanges, "qubits_swapped": [len(s[1]) for s in sim.plan.steps if s[0] == "exchange"],
+                               "bytes_sent_per_rank_per_step": xb, "seconds_per_step": xs,
+                               "xgmi_gbps_per_rank": (xb / xs / 1e9) if xs > 0 else None,
+                               "note": "seconds include the pack kernel and host-side stream hand-offs (rank 0's clock)"}
         if not args.no_cpu_baseline and args.gpus == 1:
             out["cpu_baseline"] = cpu_baseline(n, gates, args.cpu_seconds)
         print(json.dumps(out), flush=True)

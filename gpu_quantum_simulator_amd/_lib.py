@@ -91,6 +91,17 @@ def load() -> ctypes.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `make -C gpu_quantum_simulator_amd/csrc` "
                 "(or __graft_entry__.build()).  There is no fallback implementation.")
+        # torch wheels bundle their own HIP runtime (torch/lib/libamdhip64.so) next to the system one libqsim
+        # links (/opt/rocm/lib/libamdhip64.so.7).  Both can live in one process, but only if torch's copy is
+        # loaded FIRST (measured on MI355X / ROCm 7.2: the other order leaves torch with "No HIP GPUs").
+        # Anything that will also use torch (bench.py, the sharded path, the tests) therefore gets torch
+        # imported here; a process that never imports torch is unaffected.
+        import sys
+        if "torch" not in sys.modules and os.environ.get("QSIM_NO_TORCH_PRELOAD", "") == "":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = header and library disagree

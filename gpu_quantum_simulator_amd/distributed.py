@@ -228,10 +228,15 @@ class HipShard:
                 c.append_1q(np.diag([op[1], op[1]]), 0)  # per-rank scalar, folds into the next fused block
         self._compiled[key] = c
 
+    # The buffers belong to torch's HIP runtime, libqsim runs on the system one (see _lib.load): device
+    # addresses are shared process-wide, so kernels work on them directly, but host<->device copies and
+    # stream ordering stay with the runtime that owns the allocation.  Hand-offs are host-side syncs.
     def reset(self, holds_index0: bool):
         self.sim.reset()
         if not holds_index0:
-            self.sim.write(np.zeros(1, dtype=np.complex128), 0)
+            self.sim.sync()
+            self.state[0].zero_()
+            self.torch.cuda.current_stream().synchronize()
 
     def apply_local(self, key: int):
         self.sim.run(self._compiled[key])
@@ -250,10 +255,11 @@ class HipShard:
         return self.sim.norm2()
 
     def read_all(self) -> np.ndarray:
-        return self.sim.read()
+        return self.read(0, 1 << self.m)
 
     def read(self, first, count) -> np.ndarray:
-        return self.sim.read(first, count)
+        self.sim.sync()
+        return self.state[first:first + count].cpu().numpy().reshape(-1).view(np.complex128)
 
     def stats(self):
         return self.sim.stats()

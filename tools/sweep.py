@@ -63,6 +63,17 @@ def main():
     for r in rows:
         print(f"{r[0]:8s} {str(r[1]):10s} {r[2]:9.3f} ms  {r[3]:8.1f} GB/s  {r[4]}", flush=True)
 
+    if "pack" in what:
+        import torch
+        with Simulator(n, fuse=0, profile=True, grid_cap=a.grid_cap) as sim:
+            for q in range(n):
+                sim.apply_1q(H, q)
+            sim.sync()
+            dst = torch.empty((1 << n, 2), dtype=torch.float64, device="cuda")
+            for bits in ((n - 3, n - 2, n - 1), (0, 1, 2), (1, 12, 20), (5,), (n - 1,), (3, 4, 5, 6)):
+                ms, gbs, k = timed(sim, lambda: sim.pack_bits(bits, dst.data_ptr()), 5)
+                print(f"pack     {str(bits):14s} {ms:9.3f} ms  {gbs:8.1f} GB/s  {k}", flush=True)
+            del dst
     if "tile" in what:
         # tile kernel with k dense 4x4 ops on fixed high qubits, for several geometries
         for tb, tl in ((12, 7), (12, 6), (11, 7), (11, 6), (13, 7), (10, 6)):

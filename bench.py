@@ -53,8 +53,8 @@ def parse_args():
     return ap.parse_args()
 
 
-KERNEL_SYMBOL = {"tile": "qsim::k_tile<256>", "gate1": "qsim::k_gate1_hi<4, false>", "gate1_lo": "qsim::k_gate1_lo<4, false>",
-                 "gate2": "qsim::k_gate2_hh<2, false>"}
+KERNEL_SYMBOL = {"tile": "qsim::k_tile<12, 512>", "gate1": "qsim::k_gate1_hi<4, false>",
+                 "gate1_lo": "qsim::k_gate1_lo<4, false>", "gate2": "qsim::k_gate2_hh<2, false>"}
 
 
 def pmc_traffic(kernel_class, is_default_workload):

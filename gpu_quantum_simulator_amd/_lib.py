@@ -11,8 +11,8 @@ LIB_PATH = os.path.join(PKG_DIR, "libqsim.so")
 CLI_PATH = os.path.join(PKG_DIR, "bin", "qsim")
 
 QSIM_OK, ERR_ARG, ERR_ALLOC, ERR_DEVICE, ERR_OPEN, ERR_PARSE = range(6)
-GATE_U1, GATE_CX, GATE_U2 = 1, 2, 3
-OPT_FUSE, OPT_PROFILE, OPT_TILE_BITS, OPT_TILE_LOW_BITS, OPT_MAX_PENDING, OPT_TILE_MAX_OPS, OPT_GRID_CAP = range(1, 8)
+GATE_U1, GATE_CX, GATE_U2, GATE_U3 = 1, 2, 3, 4
+OPT_FUSE, OPT_PROFILE, OPT_TILE_BITS, OPT_TILE_LOW_BITS, OPT_MAX_PENDING, OPT_TILE_MAX_OPS, OPT_GRID_CAP, OPT_TILE_THREADS = range(1, 9)
 K_NAMES = ("init", "gate1", "gate1_lo", "phase", "cx", "gate2", "tile", "pack")
 K_COUNT = len(K_NAMES)
 
@@ -28,7 +28,7 @@ class QsimStats(ctypes.Structure):
                                          "ms": float(self.k_ms[k])} for k in range(K_COUNT)}}
 
 
-SCHED_CB = ctypes.CFUNCTYPE(None, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_double), c_int)
+SCHED_CB = ctypes.CFUNCTYPE(None, c_void_p, c_int, c_int, c_int, POINTER(c_int), c_int, POINTER(c_double), c_int)
 
 # every symbol include/qsim.h declares: name -> (restype, argtypes)
 _DP = POINTER(c_double)
@@ -56,6 +56,7 @@ SIGNATURES = {
     "qsim_scale": (c_int, [c_void_p, c_double, c_double]),
     "qsim_get_stats": (c_int, [c_void_p, POINTER(QsimStats)]),
     "qsim_reset_stats": (c_int, [c_void_p]),
+    "qsim_launch_log": (c_long, [c_void_p, c_long, POINTER(c_int), POINTER(c_int), POINTER(c_uint64), POINTER(c_double)]),
     "qsim_circuit_parse_file": (c_int, [c_char_p, POINTER(c_void_p)]),
     "qsim_circuit_parse_text": (c_int, [c_char_p, c_size_t, POINTER(c_void_p)]),
     "qsim_circuit_create": (c_int, [c_int, POINTER(c_void_p)]),

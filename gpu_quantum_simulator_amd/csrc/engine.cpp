@@ -53,7 +53,10 @@ struct QueuedGate {
 struct ProfEvent {
     hipEvent_t start, stop;
     int kclass;
+    int n_ops;
+    uint64_t high_mask;
 };
+struct LaunchRec { int kclass, n_ops; uint64_t high_mask; double ms; };
 
 struct qsim_state {
     int n = 0, device = 0;
@@ -61,7 +64,7 @@ struct qsim_state {
     double2 *amps = nullptr;
     bool owns = false;
     // options
-    int fuse = 3, profile = 0, tile_bits = 11, tile_low_bits = 6, tile_max_ops = 24, grid_cap = 0;
+    int fuse = 3, profile = 0, tile_bits = 12, tile_low_bits = 4, tile_max_ops = 32, grid_cap = 0, tile_threads = 0;
     long max_pending = 1L << 16;
     // queue
     std::vector<QueuedGate> queue;
@@ -72,6 +75,7 @@ struct qsim_state {
     // stats
     qsim_stats stats{};
     std::vector<ProfEvent> events;      // recorded, not yet resolved
+    std::vector<LaunchRec> launch_log;  // per-launch times since the last qsim_reset_stats (profile mode)
     std::vector<hipEvent_t> event_pool; // reusable
 };
 
@@ -150,7 +154,7 @@ extern "C" int qsim_set_option(qsim_state *s, int option, long value) {
         s->tile_bits = (int)value;
         break;
     case QSIM_OPT_TILE_LOW_BITS:
-        if (value < 4 || value > 11) return fail(QSIM_ERR_ARG, "tile_low_bits %ld not in 4..11", value);
+        if (value < 2 || value > 11) return fail(QSIM_ERR_ARG, "tile_low_bits %ld not in 2..11", value);
         s->tile_low_bits = (int)value;
         break;
     case QSIM_OPT_MAX_PENDING:
@@ -164,6 +168,11 @@ extern "C" int qsim_set_option(qsim_state *s, int option, long value) {
     case QSIM_OPT_GRID_CAP:
         if (value < 0) return fail(QSIM_ERR_ARG, "grid_cap must be >= 0");
         s->grid_cap = (int)value;
+        break;
+    case QSIM_OPT_TILE_THREADS:
+        if (value != 0 && value != 256 && value != 512 && value != 1024)
+            return fail(QSIM_ERR_ARG, "tile_threads must be 0 (auto), 256, 512 or 1024");
+        s->tile_threads = (int)value;
         break;
     default: return fail(QSIM_ERR_ARG, "unknown option %d", option);
     }
@@ -180,6 +189,7 @@ extern "C" long qsim_get_option(const qsim_state *s, int option) {
     case QSIM_OPT_MAX_PENDING: return s->max_pending;
     case QSIM_OPT_TILE_MAX_OPS: return s->tile_max_ops;
     case QSIM_OPT_GRID_CAP: return s->grid_cap;
+    case QSIM_OPT_TILE_THREADS: return s->tile_threads;
     default: return -1;
     }
 }
@@ -202,6 +212,7 @@ static int resolve_events(qsim_state *s) {
     for (auto &pe : s->events) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) s->stats.k_ms[pe.kclass] += ms;
+        if (s->launch_log.size() < (1u << 20)) s->launch_log.push_back({pe.kclass, pe.n_ops, pe.high_mask, (double)ms});
         s->event_pool.push_back(pe.start);
         s->event_pool.push_back(pe.stop);
     }
@@ -213,9 +224,11 @@ struct LaunchScope { // records a start/stop pair around one launch when profili
     qsim_state *s;
     ProfEvent pe{};
     bool on;
-    LaunchScope(qsim_state *st, int kclass) : s(st), on(st->profile != 0) {
+    LaunchScope(qsim_state *st, int kclass, int n_ops = 1, uint64_t high_mask = 0) : s(st), on(st->profile != 0) {
         if (on) {
             pe.kclass = kclass;
+            pe.n_ops = n_ops;
+            pe.high_mask = high_mask;
             pe.start = take_event(s);
             pe.stop = take_event(s);
             (void)hipEventRecord(pe.start, s->stream);
@@ -307,30 +320,63 @@ static inline int local_bit(const TileGeom &g, int q) {
     return -1;
 }
 
-static void to_tile_op(const TileGeom &g, const FusedOp &op, TileOp &t) {
+// FusedOp -> device TileOp.  Returns false when a qubit is outside the tile or the block cannot be expressed
+// (a 3-qubit block with more than 4 entries per row; merge_sparse never produces one).
+static bool to_tile_op(const TileGeom &g, const FusedOp &op, TileOp &t) {
     memset(&t, 0, sizeof t);
-    const bool diag = op.is_diag();
-    if (op.kind == OP_G1) {
-        t.b_hi = local_bit(g, op.q_hi);
-        if (diag) {
+    const int k = op.nq(), D = op.dim();
+    const int qs[3] = {op.q_hi, op.q_lo, op.q_lo2}; // most significant first
+    t.nq = k;
+    for (int a = 0; a < k; a++) {
+        const int lb = local_bit(g, qs[k - 1 - a]); // ascending
+        if (lb < 0) return false;
+        t.b[a] = lb;
+    }
+    auto nz = [&](int r, int c) { return op.m[D * r + c].real() != 0.0 || op.m[D * r + c].imag() != 0.0; };
+    auto is1 = [&](const cd &z) { return z.real() == 1.0 && z.imag() == 0.0; };
+    int maxnnz = 0;
+    for (int r = 0; r < D; r++) {
+        int cnt = 0;
+        for (int c = 0; c < D; c++) cnt += nz(r, c);
+        maxnnz = cnt > maxnnz ? cnt : maxnnz;
+    }
+    if (k == 1) {
+        if (maxnnz == 1 && nz(0, 0)) { // diagonal
             t.kind = TOP_DIAG1;
             t.re[0] = op.m[0].real(); t.im[0] = op.m[0].imag();
             t.re[1] = op.m[3].real(); t.im[1] = op.m[3].imag();
+            t.meta = is1(op.m[0]) ? 1 : 0;
         } else {
             t.kind = TOP_G1;
-            for (int k = 0; k < 4; k++) { t.re[k] = op.m[k].real(); t.im[k] = op.m[k].imag(); }
+            for (int e = 0; e < 4; e++) { t.re[e] = op.m[e].real(); t.im[e] = op.m[e].imag(); }
         }
-    } else {
-        t.b_hi = local_bit(g, op.q_hi);
-        t.b_lo = local_bit(g, op.q_lo);
-        if (diag) {
-            t.kind = TOP_DIAG2;
-            for (int k = 0; k < 4; k++) { t.re[k] = op.m[5 * k].real(); t.im[k] = op.m[5 * k].imag(); }
-        } else {
-            t.kind = TOP_G2;
-            for (int k = 0; k < 16; k++) { t.re[k] = op.m[k].real(); t.im[k] = op.m[k].imag(); }
+        return true;
+    }
+    if (k == 2 && maxnnz > 2) { // dense 4x4: register form
+        t.kind = TOP_G2;
+        for (int e = 0; e < 16; e++) { t.re[e] = op.m[e].real(); t.im[e] = op.m[e].imag(); }
+        return true;
+    }
+    if (maxnnz > 4) return false;
+    const int T = maxnnz <= 1 ? 1 : maxnnz <= 2 ? 2 : 4;
+    t.kind = TOP_SP;
+    t.terms = T;
+    for (int r = 0; r < D; r++) {
+        int j = 0;
+        for (int c = 0; c < D; c++)
+            if (nz(r, c)) {
+                const int e = r * T + j++;
+                t.colw[e >> 2] |= (uint32_t)c << (8 * (e & 3));
+                t.re[e] = op.m[D * r + c].real();
+                t.im[e] = op.m[D * r + c].imag();
+            }
+        if (j == 1 && nz(r, r) && is1(op.m[D * r + r])) t.meta |= 1 << r; // identity row: no traffic at all
+        for (; j < T; j++) { // pad with a zero coefficient on the row's own slot
+            const int e = r * T + j;
+            t.colw[e >> 2] |= (uint32_t)r << (8 * (e & 3));
         }
     }
+    return true;
 }
 
 static int launch_pass(qsim_state *s, const Pass &p) {
@@ -375,16 +421,16 @@ static int launch_pass(qsim_state *s, const Pass &p) {
             s->ops_used = 0;
         }
         TileOp *h = s->h_ops + s->ops_used;
-        for (size_t k = 0; k < need; k++) {
-            to_tile_op(p.geom, p.ops[k], h[k]);
-            if (h[k].b_hi < 0 || (p.ops[k].kind != OP_G1 && h[k].b_lo < 0))
-                return fail(QSIM_ERR_ARG, "internal: op qubit outside its tile");
-        }
+        for (size_t k = 0; k < need; k++)
+            if (!to_tile_op(p.geom, p.ops[k], h[k])) return fail(QSIM_ERR_ARG, "internal: block does not fit its tile pass");
         TileOp *d = s->d_ops + s->ops_used;
         HIP_TRY(hipMemcpyAsync(d, h, need * sizeof(TileOp), hipMemcpyHostToDevice, s->stream));
         s->ops_used += need;
-        LaunchScope scope(s, p.kclass);
-        e = launch_tile(cfg, s->amps, p.geom, d, (int)need);
+        uint64_t hm = 0;
+        for (int j = 0; j < p.geom.n_high; j++) hm |= 1ULL << p.geom.high[j];
+        LaunchScope scope(s, p.kclass, (int)need, hm);
+        const int threads = s->tile_threads; // 0: default for the tile size
+        e = launch_tile(cfg, s->amps, p.geom, d, (int)need, threads);
         break;
     }
     default: return fail(QSIM_ERR_ARG, "internal: unknown kernel class %d", p.kclass);
@@ -496,7 +542,22 @@ extern "C" int qsim_reset_stats(qsim_state *s) {
     const int rc = resolve_events(s);
     if (rc) return rc;
     memset(&s->stats, 0, sizeof s->stats);
+    s->launch_log.clear();
     return QSIM_OK;
+}
+
+extern "C" long qsim_launch_log(qsim_state *s, long index, int *kclass, int *n_ops, uint64_t *high_mask, double *ms) {
+    if (!s) return -1;
+    if (resolve_events(s)) return -1;
+    const long count = (long)s->launch_log.size();
+    if (index >= 0 && index < count) {
+        const LaunchRec &r = s->launch_log[index];
+        if (kclass) *kclass = r.kclass;
+        if (n_ops) *n_ops = r.n_ops;
+        if (high_mask) *high_mask = r.high_mask;
+        if (ms) *ms = r.ms;
+    }
+    return count;
 }
 
 // ---- circuits ------------------------------------------------------------------------------------------
@@ -537,7 +598,7 @@ static void feed(Scheduler &sched, const qsim_circuit *c) {
 extern "C" int qsim_plan_circuit(const qsim_circuit *c, int fuse, int tile_bits, int tile_low_bits, qsim_stats *out) {
     if (!c || !out) return fail(QSIM_ERR_ARG, "NULL argument");
     if (fuse < 0 || fuse > 3) return fail(QSIM_ERR_ARG, "fuse level %d not in 0..3", fuse);
-    Scheduler sched(sched_config(c->num_q, fuse, tile_bits, tile_low_bits, 24));
+    Scheduler sched(sched_config(c->num_q, fuse, tile_bits, tile_low_bits, 32));
     feed(sched, c);
     std::vector<Pass> passes;
     sched.finish(passes);
@@ -563,16 +624,17 @@ extern "C" int qsim_schedule_circuit(const qsim_circuit *c, int fuse, int tile_b
     int pi = 0;
     for (const Pass &p : passes) {
         for (const FusedOp &op : p.ops) {
-            double U[32];
-            const int cnt = op.kind == OP_G1 ? 4 : op.kind == OP_G2 ? 16 : 0;
-            for (int k = 0; k < cnt; k++) { U[2 * k] = op.m[k].real(); U[2 * k + 1] = op.m[k].imag(); }
-            if (p.kclass == QSIM_K_TILE) { // every op must lie inside the tile the pass declares
-                const bool in_hi = local_bit(p.geom, op.q_hi) >= 0;
-                const bool in_lo = op.kind == OP_G1 || local_bit(p.geom, op.q_lo) >= 0;
-                if (!in_hi || !in_lo) return fail(QSIM_ERR_ARG, "internal: op outside its tile");
+            double U[128];
+            const int d = op.kind == OP_CX ? 0 : op.dim();
+            for (int k = 0; k < d * d; k++) { U[2 * k] = op.m[k].real(); U[2 * k + 1] = op.m[k].imag(); }
+            if (p.kclass == QSIM_K_TILE) { // every block must lie inside the tile the pass declares and be expressible
+                TileOp t;
+                if (!to_tile_op(p.geom, op, t)) return fail(QSIM_ERR_ARG, "internal: block does not fit its tile pass");
             }
-            const int kind = op.kind == OP_G1 ? QSIM_GATE_U1 : op.kind == OP_CX ? QSIM_GATE_CX : QSIM_GATE_U2;
-            cb(user, pi, p.kclass, kind, op.q_hi, op.q_lo, cnt ? U : nullptr, (int)op.gates);
+            const int kind = op.kind == OP_G1 ? QSIM_GATE_U1 : op.kind == OP_CX ? QSIM_GATE_CX
+                             : op.kind == OP_G2 ? QSIM_GATE_U2 : QSIM_GATE_U3;
+            const int qs[3] = {op.q_hi, op.q_lo, op.q_lo2};
+            cb(user, pi, p.kclass, kind, qs, op.kind == OP_CX ? 2 : op.nq(), d ? U : nullptr, (int)op.gates);
         }
         pi++;
     }

@@ -267,110 +267,194 @@ __device__ __forceinline__ uint64_t deposit(uint64_t x, uint64_t mask) {
 // loads (s_load_dwordx*): the matrix lives in SGPRs / the scalar cache, not in vector registers.
 typedef const TileOp __attribute__((address_space(4))) *ConstOps;
 
-template <int THREADS>
+// Index of the k-th work item with a zero inserted at bit b (b wave-uniform): x + (x & ~((1<<b)-1)).
+__device__ __forceinline__ uint32_t ins0(uint32_t x, uint32_t himask) { return x + (x & himask); }
+
+// Generic sparse block (TOP_SP): K qubits, T entries per row, all loop bounds static.
+template <int B, int THREADS, int K, int T>
+__device__ __forceinline__ void tile_op_sparse(amp_t *lds, ConstOps ops, int oi, uint32_t tid) {
+    constexpr uint32_t E = 1u << B;
+    constexpr int R = 1 << K;
+    constexpr uint32_t NG = E / R;                                   // groups of R amplitudes in the tile
+    constexpr int GPT = NG >= (uint32_t)THREADS ? NG / THREADS : 1;  // groups per thread
+    constexpr bool FULL = NG >= (uint32_t)THREADS && NG % THREADS == 0;
+    const uint32_t b0 = (uint32_t)ops[oi].b[0], b1 = (uint32_t)ops[oi].b[1], b2 = (uint32_t)ops[oi].b[2];
+    const uint32_t skip = (uint32_t)ops[oi].meta;
+    auto slot = [&](uint32_t c) -> uint32_t { // wave-uniform: LDS index offset of slot code c
+        uint32_t o = (c & 1u) << b0;
+        if (K >= 2) o |= ((c >> 1) & 1u) << b1;
+        if (K >= 3) o |= ((c >> 2) & 1u) << b2;
+        return o;
+    };
+    uint32_t base[GPT];
+#pragma unroll
+    for (int g = 0; g < GPT; g++) {
+        uint32_t x = ins0(tid + g * THREADS, ~((1u << b0) - 1u));
+        if (K >= 2) x = ins0(x, ~((1u << b1) - 1u));
+        if (K >= 3) x = ins0(x, ~((1u << b2) - 1u));
+        base[g] = x;
+    }
+    amp_t y[GPT][R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if ((skip >> r) & 1u) continue;
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+            const int e = r * T + j;
+            const uint32_t off = slot((ops[oi].colw[e >> 2] >> (8 * (e & 3))) & 0xffu);
+            const double cr = ops[oi].re[e], ci = ops[oi].im[e];
+#pragma unroll
+            for (int g = 0; g < GPT; g++)
+                if (FULL || tid + g * THREADS < NG) {
+                    const amp_t x = lds[base[g] | off];
+                    y[g][r] = j == 0 ? cmul(x, cr, ci) : cfma(x, cr, ci, y[g][r]);
+                }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if ((skip >> r) & 1u) continue;
+        const uint32_t off = slot((uint32_t)r);
+#pragma unroll
+        for (int g = 0; g < GPT; g++)
+            if (FULL || tid + g * THREADS < NG) lds[base[g] | off] = y[g][r];
+    }
+}
+
+// B (tile size) and THREADS are compile-time so every per-thread loop has a static trip count: all LDS
+// reads of an op are issued before its arithmetic, all writes after, and there is no loop bookkeeping.
+template <int B, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_tile(amp_t *__restrict__ v, TileDev g, const TileOp *__restrict__ ops_g,
                                                   int n_ops, uint64_t ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     amp_t *lds = reinterpret_cast<amp_t *>(smem);
-    const int B = g.tile_bits, L = g.low_bits, H = g.n_high;
+    constexpr uint32_t E = 1u << B;
+    constexpr int APT = (E + THREADS - 1) / THREADS;                              // amplitudes per thread
+    constexpr int PPT = E / 2 >= THREADS ? (E / 2) / THREADS : 1;                  // pairs per thread
+    constexpr int QPT = E / 4 >= THREADS ? (E / 4) / THREADS : 1;                  // quads per thread
+    constexpr bool FULL = E / 4 >= THREADS && (E / 4) % THREADS == 0;              // no tail guards needed
+    const int L = g.low_bits, H = g.n_high;
     uint64_t *hoff = reinterpret_cast<uint64_t *>(smem + ((size_t)16 << B));
     ConstOps ops = (ConstOps)(uintptr_t)ops_g;
     const uint32_t tid = threadIdx.x;
     const uint32_t lowmask = (1u << L) - 1u;
-    const uint32_t E = 1u << B;
     const uint64_t nmask = g.n >= 64 ? ~0ULL : ((1ULL << g.n) - 1ULL);
     const uint64_t outer_mask = nmask & ~(g.high_mask | (uint64_t)lowmask);
 
     for (uint32_t j = tid; j < (1u << H); j += THREADS) hoff[j] = deposit(j, g.high_mask);
     __syncthreads();
 
+    // One tile per workgroup (a grid-stride loop only when the grid is capped).  Measured alternatives that lost:
+    // a persistent grid that prefetches the next tile into registers during the op phase (even with loader /
+    // storer wave roles so that s_waitcnt vmcnt stays exact): the extra 64 VGPRs halve the resident workgroups
+    // and the chip is already queue-limited on HBM, 11.4 vs 7.8 ms per pass at n = 30.
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint64_t base = deposit(tile, outer_mask); // wave-uniform
-
-        // stage in: CH independent 16-B loads in flight per lane, then CH LDS stores
-        constexpr int CH = 8;
-        for (uint32_t e0 = tid; e0 < E; e0 += THREADS * CH) {
-            amp_t r[CH];
+        {   // stage in: every load of the thread in flight before the first LDS store
+            amp_t r[APT];
 #pragma unroll
-            for (int k = 0; k < CH; k++) {
-                const uint32_t e = e0 + k * THREADS;
-                r[k] = e < E ? v[base | hoff[e >> L] | (uint64_t)(e & lowmask)] : amp_t{0.0, 0.0};
+            for (int k = 0; k < APT; k++) {
+                const uint32_t e = tid + k * THREADS;
+                r[k] = (FULL || e < E) ? v[base | hoff[e >> L] | (uint64_t)(e & lowmask)] : amp_t{0.0, 0.0};
             }
 #pragma unroll
-            for (int k = 0; k < CH; k++) {
-                const uint32_t e = e0 + k * THREADS;
-                if (e < E) lds[e] = r[k];
+            for (int k = 0; k < APT; k++) {
+                const uint32_t e = tid + k * THREADS;
+                if (FULL || e < E) lds[e] = r[k];
             }
         }
         __syncthreads();
 
         for (int oi = 0; oi < n_ops; oi++) {
             const int kind = ops[oi].kind;
-            if (kind == TOP_G1) {
-                const int b = ops[oi].b_hi;
-                const double u0r = ops[oi].re[0], u0i = ops[oi].im[0], u1r = ops[oi].re[1], u1i = ops[oi].im[1];
-                const double u2r = ops[oi].re[2], u2i = ops[oi].im[2], u3r = ops[oi].re[3], u3i = ops[oi].im[3];
-#pragma unroll 4
-                for (uint32_t p = tid; p < (E >> 1); p += THREADS) {
-                    const uint32_t i0 = (uint32_t)insert_zero(p, b), i1 = i0 | (1u << b);
-                    const amp_t a0 = lds[i0], a1 = lds[i1];
-                    lds[i0] = cfma(a1, u1r, u1i, cmul(a0, u0r, u0i));
-                    lds[i1] = cfma(a1, u3r, u3i, cmul(a0, u2r, u2i));
+            if (kind == TOP_SP) {
+                const int nq = ops[oi].nq, terms = ops[oi].terms;
+                if (nq == 2) {
+                    if (terms == 1) tile_op_sparse<B, THREADS, 2, 1>(lds, ops, oi, tid);
+                    else tile_op_sparse<B, THREADS, 2, 2>(lds, ops, oi, tid);
+                } else {
+                    if (terms == 1) tile_op_sparse<B, THREADS, 3, 1>(lds, ops, oi, tid);
+                    else if (terms == 2) tile_op_sparse<B, THREADS, 3, 2>(lds, ops, oi, tid);
+                    else tile_op_sparse<B, THREADS, 3, 4>(lds, ops, oi, tid);
                 }
             } else if (kind == TOP_G2) {
-                const int bl = ops[oi].b_lo, bh = ops[oi].b_hi;
+                const uint32_t bl = (uint32_t)ops[oi].b[0], bh = (uint32_t)ops[oi].b[1];
+                const uint32_t hm_lo = ~((1u << bl) - 1u), hm_hi = ~((1u << bh) - 1u);
+                const uint32_t o1 = 1u << bl, o2 = 1u << bh, o3 = o1 | o2;
                 double ur[16], ui[16];
 #pragma unroll
                 for (int k = 0; k < 16; k++) { ur[k] = ops[oi].re[k]; ui[k] = ops[oi].im[k]; }
-#pragma unroll 2
-                for (uint32_t p = tid; p < (E >> 2); p += THREADS) {
-                    const uint32_t i00 = (uint32_t)insert_zero(insert_zero(p, bl), bh);
-                    const uint32_t i01 = i00 | (1u << bl), i10 = i00 | (1u << bh), i11 = i10 | (1u << bl);
-                    const amp_t x0 = lds[i00], x1 = lds[i01], x2 = lds[i10], x3 = lds[i11];
-                    amp_t y[4];
+                uint32_t i00[QPT];
+                amp_t x[QPT][4];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        amp_t acc = cmul(x0, ur[4 * r], ui[4 * r]);
-                        acc = cfma(x1, ur[4 * r + 1], ui[4 * r + 1], acc);
-                        acc = cfma(x2, ur[4 * r + 2], ui[4 * r + 2], acc);
-                        acc = cfma(x3, ur[4 * r + 3], ui[4 * r + 3], acc);
-                        y[r] = acc;
+                for (int k = 0; k < QPT; k++) {
+                    i00[k] = ins0(ins0(tid + k * THREADS, hm_lo), hm_hi);
+                    if (FULL || tid + k * THREADS < E / 4) {
+                        x[k][0] = lds[i00[k]]; x[k][1] = lds[i00[k] | o1]; x[k][2] = lds[i00[k] | o2]; x[k][3] = lds[i00[k] | o3];
                     }
-                    lds[i00] = y[0];
-                    lds[i01] = y[1];
-                    lds[i10] = y[2];
-                    lds[i11] = y[3];
                 }
-            } else if (kind == TOP_DIAG1) {
-                const int b = ops[oi].b_hi;
+#pragma unroll
+                for (int k = 0; k < QPT; k++)
+                    if (FULL || tid + k * THREADS < E / 4) {
+                        amp_t y[4];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            amp_t acc = cmul(x[k][0], ur[4 * r], ui[4 * r]);
+                            acc = cfma(x[k][1], ur[4 * r + 1], ui[4 * r + 1], acc);
+                            acc = cfma(x[k][2], ur[4 * r + 2], ui[4 * r + 2], acc);
+                            acc = cfma(x[k][3], ur[4 * r + 3], ui[4 * r + 3], acc);
+                            y[r] = acc;
+                        }
+                        lds[i00[k]] = y[0]; lds[i00[k] | o1] = y[1]; lds[i00[k] | o2] = y[2]; lds[i00[k] | o3] = y[3];
+                    }
+            } else if (kind == TOP_G1) {
+                const uint32_t bh = (uint32_t)ops[oi].b[0];
+                const uint32_t hm = ~((1u << bh) - 1u), o1 = 1u << bh;
+                const double u0r = ops[oi].re[0], u0i = ops[oi].im[0], u1r = ops[oi].re[1], u1i = ops[oi].im[1];
+                const double u2r = ops[oi].re[2], u2i = ops[oi].im[2], u3r = ops[oi].re[3], u3i = ops[oi].im[3];
+                uint32_t i0[PPT];
+                amp_t a0[PPT], a1[PPT];
+#pragma unroll
+                for (int k = 0; k < PPT; k++) {
+                    i0[k] = ins0(tid + k * THREADS, hm);
+                    if (FULL || tid + k * THREADS < E / 2) { a0[k] = lds[i0[k]]; a1[k] = lds[i0[k] | o1]; }
+                }
+#pragma unroll
+                for (int k = 0; k < PPT; k++)
+                    if (FULL || tid + k * THREADS < E / 2) {
+                        lds[i0[k]] = cfma(a1[k], u1r, u1i, cmul(a0[k], u0r, u0i));
+                        lds[i0[k] | o1] = cfma(a1[k], u3r, u3i, cmul(a0[k], u2r, u2i));
+                    }
+            } else { // TOP_DIAG1
+                const uint32_t bh = (uint32_t)ops[oi].b[0];
+                const uint32_t hm = ~((1u << bh) - 1u), o1 = 1u << bh;
                 const double d0r = ops[oi].re[0], d0i = ops[oi].im[0], d1r = ops[oi].re[1], d1i = ops[oi].im[1];
-#pragma unroll 4
-                for (uint32_t e = tid; e < E; e += THREADS) {
-                    const bool up = (e >> b) & 1u;
-                    lds[e] = cmul(lds[e], up ? d1r : d0r, up ? d1i : d0i);
+                const bool unit0 = ops[oi].meta & 1;
+                uint32_t i0[PPT];
+                amp_t a0[PPT], a1[PPT];
+#pragma unroll
+                for (int k = 0; k < PPT; k++) {
+                    i0[k] = ins0(tid + k * THREADS, hm);
+                    if (FULL || tid + k * THREADS < E / 2) {
+                        if (!unit0) a0[k] = lds[i0[k]];
+                        a1[k] = lds[i0[k] | o1];
+                    }
                 }
-            } else { // TOP_DIAG2
-                const int bl = ops[oi].b_lo, bh = ops[oi].b_hi;
-                const double e0r = ops[oi].re[0], e0i = ops[oi].im[0], e1r = ops[oi].re[1], e1i = ops[oi].im[1];
-                const double e2r = ops[oi].re[2], e2i = ops[oi].im[2], e3r = ops[oi].re[3], e3i = ops[oi].im[3];
-#pragma unroll 4
-                for (uint32_t e = tid; e < E; e += THREADS) {
-                    const bool hi = (e >> bh) & 1u, lo = (e >> bl) & 1u;
-                    const double dr = hi ? (lo ? e3r : e2r) : (lo ? e1r : e0r);
-                    const double di = hi ? (lo ? e3i : e2i) : (lo ? e1i : e0i);
-                    lds[e] = cmul(lds[e], dr, di);
-                }
+#pragma unroll
+                for (int k = 0; k < PPT; k++)
+                    if (FULL || tid + k * THREADS < E / 2) {
+                        if (!unit0) lds[i0[k]] = cmul(a0[k], d0r, d0i);
+                        lds[i0[k] | o1] = cmul(a1[k], d1r, d1i);
+                    }
             }
             __syncthreads();
         }
 
         // stage out
-        for (uint32_t e0 = tid; e0 < E; e0 += THREADS * CH) {
 #pragma unroll
-            for (int k = 0; k < CH; k++) {
-                const uint32_t e = e0 + k * THREADS;
-                if (e < E) v[base | hoff[e >> L] | (uint64_t)(e & lowmask)] = lds[e];
-            }
+        for (int k = 0; k < APT; k++) {
+            const uint32_t e = tid + k * THREADS;
+            if (FULL || e < E) v[base | hoff[e >> L] | (uint64_t)(e & lowmask)] = lds[e];
         }
         __syncthreads();
     }
@@ -519,14 +603,15 @@ hipError_t launch_gate2(const LaunchCfg &cfg, double2 *v, int n, int q_hi, int q
     return hipGetLastError();
 }
 
-int tile_lds_bytes(int tile_bits) { return (16 << tile_bits) + (8 << kMaxTileHigh); }
+int tile_lds_bytes(int tile_bits, int n_high) { return (16 << tile_bits) + (8 << n_high); }
 
-hipError_t launch_tile(const LaunchCfg &cfg, double2 *v, const TileGeom &g, const TileOp *d_ops, int n_ops) {
+template <int B, int THREADS>
+static hipError_t launch_tile_t(const LaunchCfg &cfg, double2 *v, const TileGeom &g, const TileOp *d_ops, int n_ops) {
     const uint64_t ntiles = 1ULL << (g.n - g.tile_bits);
-    const int lds = tile_lds_bytes(g.tile_bits);
+    const int lds = tile_lds_bytes(g.tile_bits, g.n_high);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<TPB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<B, THREADS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -535,9 +620,36 @@ hipError_t launch_tile(const LaunchCfg &cfg, double2 *v, const TileGeom &g, cons
     td.tile_bits = g.tile_bits; td.low_bits = g.low_bits; td.n_high = g.n_high; td.n = g.n;
     td.high_mask = 0;
     for (int j = 0; j < g.n_high; j++) td.high_mask |= 1ULL << g.high[j];
-    hipLaunchKernelGGL(k_tile<TPB>, dim3(grid_for(cfg, ntiles)), dim3(TPB), lds, cfg.stream, (amp_t *)v, td, d_ops, n_ops,
-                       ntiles);
+    hipLaunchKernelGGL((k_tile<B, THREADS>), dim3(grid_for(cfg, ntiles)), dim3(THREADS), lds, cfg.stream, (amp_t *)v, td,
+                       d_ops, n_ops, ntiles);
     return hipGetLastError();
+}
+
+// threads: 0 = the default for the tile size.  Tiles below 2^8 amplitudes (tiny registers) use the 2^8 kernel's
+// tail guards with a smaller E, so every size from 1 to 13 bits has an instantiation.
+hipError_t launch_tile(const LaunchCfg &cfg, double2 *v, const TileGeom &g, const TileOp *d_ops, int n_ops, int threads) {
+    switch (g.tile_bits) {
+    case 0: return launch_tile_t<0, 64>(cfg, v, g, d_ops, n_ops);
+    case 1: return launch_tile_t<1, 64>(cfg, v, g, d_ops, n_ops);
+    case 2: return launch_tile_t<2, 64>(cfg, v, g, d_ops, n_ops);
+    case 3: return launch_tile_t<3, 64>(cfg, v, g, d_ops, n_ops);
+    case 4: return launch_tile_t<4, 64>(cfg, v, g, d_ops, n_ops);
+    case 5: return launch_tile_t<5, 64>(cfg, v, g, d_ops, n_ops);
+    case 6: return launch_tile_t<6, 64>(cfg, v, g, d_ops, n_ops);
+    case 7: return launch_tile_t<7, 64>(cfg, v, g, d_ops, n_ops);
+    case 8: return launch_tile_t<8, 64>(cfg, v, g, d_ops, n_ops);
+    case 9: return launch_tile_t<9, 128>(cfg, v, g, d_ops, n_ops);
+    case 10: return threads == 512 ? launch_tile_t<10, 512>(cfg, v, g, d_ops, n_ops) : launch_tile_t<10, 256>(cfg, v, g, d_ops, n_ops);
+    case 11: return threads == 512 ? launch_tile_t<11, 512>(cfg, v, g, d_ops, n_ops) : launch_tile_t<11, 256>(cfg, v, g, d_ops, n_ops);
+    case 12:
+        if (threads == 256) return launch_tile_t<12, 256>(cfg, v, g, d_ops, n_ops);
+        if (threads == 1024) return launch_tile_t<12, 1024>(cfg, v, g, d_ops, n_ops);
+        return launch_tile_t<12, 512>(cfg, v, g, d_ops, n_ops);
+    case 13:
+        if (threads == 512) return launch_tile_t<13, 512>(cfg, v, g, d_ops, n_ops);
+        return launch_tile_t<13, 1024>(cfg, v, g, d_ops, n_ops);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_norm2(const LaunchCfg &cfg, const double2 *v, int n, double *d_out) {

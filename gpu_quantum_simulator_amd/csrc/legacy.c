@@ -27,7 +27,8 @@ int qsim_apply_env_options(qsim_state *s) {
     static const struct { const char *env; int opt; } map[] = {
         {"QSIM_FUSE", QSIM_OPT_FUSE}, {"QSIM_TILE_BITS", QSIM_OPT_TILE_BITS},
         {"QSIM_TILE_LOW_BITS", QSIM_OPT_TILE_LOW_BITS}, {"QSIM_TILE_MAX_OPS", QSIM_OPT_TILE_MAX_OPS},
-        {"QSIM_GRID_CAP", QSIM_OPT_GRID_CAP}, {"QSIM_PROFILE", QSIM_OPT_PROFILE}};
+        {"QSIM_GRID_CAP", QSIM_OPT_GRID_CAP}, {"QSIM_PROFILE", QSIM_OPT_PROFILE},
+        {"QSIM_TILE_THREADS", QSIM_OPT_TILE_THREADS}};
     for (size_t i = 0; i < sizeof map / sizeof map[0]; i++) {
         const char *v = getenv(map[i].env);
         if (v && *v) {

@@ -14,19 +14,31 @@ namespace qsim {
 struct M2 { double re[4], im[4]; };
 struct M4 { double re[16], im[16]; };
 
-// One fused block inside a cache-blocked pass.  Bit positions are TILE-LOCAL (see TileGeom).
-enum : int32_t { TOP_G1 = 1, TOP_G2 = 2, TOP_DIAG1 = 3, TOP_DIAG2 = 4 };
+// One fused block inside a cache-blocked pass.  Bit positions are TILE-LOCAL (see TileGeom), ascending:
+// b[0] is the block's lowest qubit = bit 0 of a slot code, b[k-1] its highest = the slot code's top bit.
+//   TOP_G1     dense 2x2 on b[0]                      re/im[0..3] row-major
+//   TOP_DIAG1  diag(d0, d1) on b[0]                   re/im[0..1]; meta bit 0: d0 == 1 (only the bit=1 half moves)
+//   TOP_G2     dense 4x4 on (b[1], b[0])              re/im[0..15] row-major, operands held in registers
+//   TOP_SP     sparse 2^k x 2^k block, k = nq in {2,3}: every row r has `terms` (1, 2 or 4) entries
+//              y[r] = sum_j coef[r*terms + j] * x[col[r*terms + j]], operands fetched straight from their LDS slots
+//              (wave-uniform offsets); rows with meta bit r set are untouched (identity row) and cost nothing.
+//              Most fused clusters of Clifford+T-like circuits are permutations times phases or two independent
+//              2x2 blocks, and so are products of neighbouring ones on <= 3 qubits (Scheduler::merge_sparse).
+enum : int32_t { TOP_G1 = 1, TOP_G2 = 2, TOP_DIAG1 = 3, TOP_SP = 4 };
 struct TileOp {
     int32_t kind;
-    int32_t b_hi;     // tile-local bit of the high qubit (G2/DIAG2) or the target (G1/DIAG1)
-    int32_t b_lo;     // tile-local bit of the low qubit (G2/DIAG2), unused otherwise
+    int32_t nq;       // qubits of the block (1..3)
+    int32_t b[3];     // tile-local bits, ascending
+    int32_t terms;    // TOP_SP: entries per row (1, 2, 4)
+    int32_t meta;     // see above
     int32_t pad;
-    double re[16];    // row-major; G1 uses [0..3], DIAG1 [0..1], DIAG2 [0..3]
-    double im[16];
+    uint32_t colw[8]; // TOP_SP: slot code of entry e in byte e%4 of colw[e/4]
+    double re[32];
+    double im[32];
 };
-static_assert(sizeof(TileOp) == 272, "TileOp layout is shared with the device");
+static_assert(sizeof(TileOp) == 576, "TileOp layout is shared with the device");
 
-constexpr int kMaxTileHigh = 8; // high (non-contiguous) qubits per tile
+constexpr int kMaxTileHigh = 10; // high (non-contiguous) qubits per tile
 struct TileGeom {
     int32_t tile_bits;          // B: log2 amplitudes per tile
     int32_t low_bits;           // L: tile-local bits [0,L) are global bits [0,L)
@@ -48,13 +60,13 @@ hipError_t launch_diag1_full(const LaunchCfg &cfg, double2 *v, int n, int q, dou
                              double d1i);
 hipError_t launch_cx(const LaunchCfg &cfg, double2 *v, int n, int control, int target);
 hipError_t launch_gate2(const LaunchCfg &cfg, double2 *v, int n, int q_hi, int q_lo, const M4 &U);
-hipError_t launch_tile(const LaunchCfg &cfg, double2 *v, const TileGeom &g, const TileOp *d_ops, int n_ops);
+hipError_t launch_tile(const LaunchCfg &cfg, double2 *v, const TileGeom &g, const TileOp *d_ops, int n_ops, int threads);
 hipError_t launch_norm2(const LaunchCfg &cfg, const double2 *v, int n, double *d_out /* zeroed */);
 // out[dst] = in[src]: dst = (block << (n-p)) | rest, where block = the p bits of src at positions
 // `bits` (ascending) and rest = the remaining n-p bits of src in order.
 hipError_t launch_pack(const LaunchCfg &cfg, const double2 *in, double2 *out, int n, const int *bits, int p);
 
-int tile_lds_bytes(int tile_bits);
+int tile_lds_bytes(int tile_bits, int n_high);
 
 } // namespace qsim
 #endif

@@ -13,21 +13,31 @@ static inline bool is_zero(const cd &z) { return z.real() == 0.0 && z.imag() == 
 static inline bool is_one(const cd &z) { return z.real() == 1.0 && z.imag() == 0.0; }
 
 bool FusedOp::is_diag() const {
-    if (kind == OP_G1) return is_zero(m[1]) && is_zero(m[2]);
-    if (kind == OP_G2) {
-        for (int r = 0; r < 4; r++)
-            for (int c = 0; c < 4; c++)
-                if (r != c && !is_zero(m[4 * r + c])) return false;
-        return true;
+    if (kind == OP_CX) return false;
+    const int d = dim();
+    for (int r = 0; r < d; r++)
+        for (int c = 0; c < d; c++)
+            if (r != c && !is_zero(m[d * r + c])) return false;
+    return true;
+}
+
+int FusedOp::max_row_nnz() const {
+    if (kind == OP_CX) return 1;
+    const int d = dim();
+    int best = 0;
+    for (int r = 0; r < d; r++) {
+        int cnt = 0;
+        for (int c = 0; c < d; c++) cnt += !is_zero(m[d * r + c]);
+        best = std::max(best, cnt);
     }
-    return false;
+    return best;
 }
 
 // EXACT identity only: the reference's isIdentity tolerance of 1e-3 (quantum_simulator_4x4.cu:247-250)
 // silently drops and reorders small rotations.
 bool FusedOp::is_identity() const {
     if (!is_diag()) return false;
-    const int d = kind == OP_G1 ? 2 : 4;
+    const int d = dim();
     for (int r = 0; r < d; r++)
         if (!is_one(m[(d + 1) * r])) return false;
     return true;
@@ -212,11 +222,9 @@ void Scheduler::tile_pass(const std::vector<FusedOp> &ops, std::vector<Pass> &ou
     p.kclass = QSIM_K_TILE;
     p.ops = ops;
     p.bytes = 32.0 * (double)(1ULL << cfg_.n);
+    if (cfg_.merge && p.ops.size() > 1) merge_sparse(p.ops);
     uint64_t high = 0;
-    for (const FusedOp &op : ops) {
-        if (op.q_hi >= L) high |= 1ULL << op.q_hi;
-        if (op.kind != OP_G1 && op.q_lo >= L) high |= 1ULL << op.q_lo;
-    }
+    for (const FusedOp &op : p.ops) high |= op.qmask() & ~((1ULL << L) - 1ULL);
     // unused slots take the lowest free bits: longer contiguous runs for the same LDS footprint
     for (int b = L; b < cfg_.n && __builtin_popcountll(high) < B - L; b++) high |= 1ULL << b;
     p.geom.tile_bits = L + __builtin_popcountll(high);
@@ -250,8 +258,7 @@ void Scheduler::build_passes(std::vector<Pass> &out) {
         for (size_t i = first; i < end; i++) {
             if (done[i]) continue;
             const FusedOp &op = closed_[i];
-            uint64_t qmask = 1ULL << op.q_hi;
-            if (op.kind != OP_G1) qmask |= 1ULL << op.q_lo;
+            const uint64_t qmask = op.qmask();
             if (qmask & blocked) { blocked |= qmask; continue; }
             const uint64_t need = qmask & ~lowmask & ~hset;
             if (__builtin_popcountll(hset) + __builtin_popcountll(need) <= kmax &&
@@ -273,6 +280,86 @@ void Scheduler::build_passes(std::vector<Pass> &out) {
             tile_pass(group, out);
         }
     }
+}
+
+// ---- sparse merging inside a pass -------------------------------------------------------------------------
+// Most fused clusters are permutations-times-phases or two independent 2x2 blocks (exact zeros), so the product
+// of neighbours on <= 3 qubits usually still has <= 4 entries per row.  Such a product costs ONE trip through
+// LDS in k_tile instead of one per factor, which is what bounds a pass once it carries more than ~6 blocks.
+// Order: a block may hop over earlier blocks it shares no qubit with (they commute); everything it shares a
+// qubit with and cannot join blocks those qubits for the rest of the scan.
+namespace {
+
+// embeds `op` (on its own qubits) into the space of qubits `qs` (descending), writing a (1<<k) x (1<<k) matrix
+void embed(const FusedOp &op, const int *qs, int k, cd *out) {
+    const int D = 1 << k, d = op.dim();
+    int opq[3] = {op.q_hi, op.q_lo, op.q_lo2};
+    int pos[3] = {0, 0, 0}; // bit position (inside the k-bit index) of each op qubit
+    for (int a = 0; a < op.nq(); a++)
+        for (int b = 0; b < k; b++)
+            if (qs[b] == opq[a]) pos[a] = k - 1 - b;
+    int opmask = 0;
+    for (int a = 0; a < op.nq(); a++) opmask |= 1 << pos[a];
+    auto sub = [&](int idx) { // index of `idx` restricted to the op's qubits, most significant first
+        int v = 0;
+        for (int a = 0; a < op.nq(); a++) v = (v << 1) | ((idx >> pos[a]) & 1);
+        return v;
+    };
+    for (int r = 0; r < D; r++)
+        for (int c = 0; c < D; c++)
+            out[D * r + c] = ((r & ~opmask) == (c & ~opmask)) ? op.m[d * sub(r) + sub(c)] : cd(0, 0);
+}
+
+} // namespace
+
+void Scheduler::merge_sparse(std::vector<FusedOp> &ops) const {
+    constexpr int kMaxQ = 3, kMaxNnz = 4;
+    std::vector<FusedOp> rem(ops), next, out;
+    while (!rem.empty()) {
+        FusedOp cur = rem[0];
+        uint64_t blocked = 0;
+        next.clear();
+        for (size_t i = 1; i < rem.size(); i++) {
+            const FusedOp &op = rem[i];
+            const uint64_t qm = op.qmask();
+            if (qm & blocked) { blocked |= qm; next.push_back(op); continue; }
+            const uint64_t un = cur.qmask() | qm;
+            bool merged = false;
+            if (__builtin_popcountll(un) <= kMaxQ && cur.kind != OP_CX && op.kind != OP_CX &&
+                cur.max_row_nnz() * op.max_row_nnz() <= 2 * kMaxNnz) {
+                int qs[3], k = 0;
+                for (int b = 63; b >= 0; b--)
+                    if (un >> b & 1ULL) qs[k++] = b;
+                const int D = 1 << k;
+                cd a[64], b2[64], prod[64];
+                embed(cur, qs, k, a);
+                embed(op, qs, k, b2);
+                for (int r = 0; r < D; r++)
+                    for (int c = 0; c < D; c++) {
+                        cd acc(0, 0);
+                        for (int t = 0; t < D; t++)
+                            if (!is_zero(b2[D * r + t]) && !is_zero(a[D * t + c])) acc += b2[D * r + t] * a[D * t + c];
+                        prod[D * r + c] = acc;
+                    }
+                FusedOp m;
+                m.kind = k == 1 ? OP_G1 : k == 2 ? OP_G2 : OP_G3;
+                m.q_hi = qs[0];
+                m.q_lo = k > 1 ? qs[1] : -1;
+                m.q_lo2 = k > 2 ? qs[2] : -1;
+                std::copy(prod, prod + D * D, m.m);
+                m.gates = cur.gates + op.gates;
+                // a 3-qubit product is only worth it while it stays sparse; 1- and 2-qubit products always fold
+                if (k <= 2 || m.max_row_nnz() <= kMaxNnz) {
+                    cur = m;
+                    merged = true;
+                }
+            }
+            if (!merged) { blocked |= qm; next.push_back(op); }
+        }
+        if (!cur.is_identity()) out.push_back(cur);
+        rem.swap(next);
+    }
+    ops.swap(out);
 }
 
 } // namespace qsim

@@ -20,15 +20,25 @@ namespace qsim {
 
 using cd = std::complex<double>;
 
-enum OpKind : int { OP_G1 = 1, OP_CX = 2, OP_G2 = 3 };
+enum OpKind : int { OP_G1 = 1, OP_CX = 2, OP_G2 = 3, OP_G3 = 4 };
 
 struct FusedOp {
     int kind = 0;
-    int q_hi = -1; // OP_G1: target; OP_CX: control; OP_G2: high qubit
-    int q_lo = -1; // OP_CX: target; OP_G2: low qubit
-    cd m[16];      // OP_G1: 2x2 in m[0..3]; OP_G2: 4x4 row-major, index = (bit q_hi, bit q_lo)
+    int q_hi = -1;  // OP_G1: target; OP_CX: control; OP_G2/OP_G3: highest qubit
+    int q_lo = -1;  // OP_CX: target; OP_G2: low qubit; OP_G3: middle qubit
+    int q_lo2 = -1; // OP_G3: lowest qubit
+    cd m[64];       // row-major 2x2 / 4x4 / 8x8; index bits = (q_hi, q_lo[, q_lo2]), most significant first
     uint32_t gates = 0;
 
+    int nq() const { return kind == OP_G1 ? 1 : kind == OP_G3 ? 3 : 2; }
+    int dim() const { return 1 << nq(); }
+    uint64_t qmask() const {
+        uint64_t m = 1ULL << q_hi;
+        if (kind != OP_G1) m |= 1ULL << q_lo;
+        if (kind == OP_G3) m |= 1ULL << q_lo2;
+        return m;
+    }
+    int max_row_nnz() const; // exact-zero structure
     bool is_diag() const;
     bool is_identity() const;
 };
@@ -44,10 +54,11 @@ struct Pass {
 struct SchedConfig {
     int n = 0;
     int fuse = 3;
-    int tile_bits = 11;
-    int tile_low_bits = 6;
-    int tile_max_ops = 24;
+    int tile_bits = 12;
+    int tile_low_bits = 4;
+    int tile_max_ops = 32;
     int window = 4096; // clusters scanned ahead when grouping a pass
+    int merge = 1;     // level 3: merge neighbouring blocks of a pass into sparse <=3-qubit blocks
 };
 
 class Scheduler {
@@ -78,6 +89,7 @@ class Scheduler {
     void build_passes(std::vector<Pass> &out);
     void single_op_pass(const FusedOp &op, std::vector<Pass> &out) const;
     void tile_pass(const std::vector<FusedOp> &ops, std::vector<Pass> &out) const;
+    void merge_sparse(std::vector<FusedOp> &ops) const;
 };
 
 } // namespace qsim

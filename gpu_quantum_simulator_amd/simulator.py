@@ -101,22 +101,23 @@ class Circuit:
             return ("cx", q0.value, q1.value)
         return ("u2", q0.value, q1.value, u.view(np.complex128).reshape(4, 4).copy())
 
-    def plan(self, fuse: int = 3, tile_bits: int = 11, tile_low_bits: int = 6) -> dict:
+    def plan(self, fuse: int = 3, tile_bits: int = 12, tile_low_bits: int = 4) -> dict:
         st = QsimStats()
         check(_lib.load().qsim_plan_circuit(self._h, fuse, tile_bits, tile_low_bits, byref(st)))
         return st.as_dict()
 
-    def schedule(self, fuse: int = 3, tile_bits: int = 11, tile_low_bits: int = 6, tile_max_ops: int = 24) -> list:
-        """Fused blocks in launch order: (pass, kernel_class, kind, q0, q1, matrix|None, gates_folded)."""
+    def schedule(self, fuse: int = 3, tile_bits: int = 12, tile_low_bits: int = 4, tile_max_ops: int = 32) -> list:
+        """Fused blocks in launch order: (pass, kernel_class, kind, qubits, matrix|None, gates_folded); kind is
+        "u1" / "cx" / "u2" / "u3", qubits most significant first (cx: control, target)."""
         out = []
 
-        def cb(_user, pass_i, kclass, kind, q0, q1, U, folded):
+        def cb(_user, pass_i, kclass, kind, qubits, nq, U, folded):
+            qs = tuple(qubits[i] for i in range(nq))
             m = None
-            if kind == _lib.GATE_U1:
-                m = np.ctypeslib.as_array(U, shape=(8,)).copy().view(np.complex128).reshape(2, 2)
-            elif kind == _lib.GATE_U2:
-                m = np.ctypeslib.as_array(U, shape=(32,)).copy().view(np.complex128).reshape(4, 4)
-            out.append((pass_i, _lib.K_NAMES[kclass], {1: "u1", 2: "cx", 3: "u2"}[kind], q0, q1, m, folded))
+            if kind != _lib.GATE_CX:
+                d = 1 << nq
+                m = np.ctypeslib.as_array(U, shape=(2 * d * d,)).copy().view(np.complex128).reshape(d, d)
+            out.append((pass_i, _lib.K_NAMES[kclass], {1: "u1", 2: "cx", 3: "u2", 4: "u3"}[kind], qs, m, folded))
 
         check(_lib.load().qsim_schedule_circuit(self._h, fuse, tile_bits, tile_low_bits, tile_max_ops,
                                                 _lib.SCHED_CB(cb), None))
@@ -152,7 +153,7 @@ class Simulator:
             self.set_option(_lib.OPT_PROFILE, 1)
         names = {"tile_bits": _lib.OPT_TILE_BITS, "tile_low_bits": _lib.OPT_TILE_LOW_BITS,
                  "max_pending": _lib.OPT_MAX_PENDING, "tile_max_ops": _lib.OPT_TILE_MAX_OPS,
-                 "grid_cap": _lib.OPT_GRID_CAP}
+                 "grid_cap": _lib.OPT_GRID_CAP, "tile_threads": _lib.OPT_TILE_THREADS}
         # tile_low_bits first when shrinking, tile_bits first when growing: keep every intermediate valid
         for key in sorted(options, key=lambda k: k != "tile_low_bits"):
             self.set_option(names[key], options[key])
@@ -238,6 +239,18 @@ class Simulator:
         st = QsimStats()
         check(_lib.load().qsim_get_stats(self._h, byref(st)))
         return st.as_dict()
+
+    def launch_log(self) -> list:
+        """[(kernel, n_ops, high_mask, ms)] per launch since reset_stats (profile mode)."""
+        from ctypes import c_uint64
+        lib = _lib.load()
+        n = lib.qsim_launch_log(self._h, -1, None, None, None, None)
+        out = []
+        for i in range(max(n, 0)):
+            k, o, hm, ms = c_int(), c_int(), c_uint64(), c_double()
+            lib.qsim_launch_log(self._h, i, byref(k), byref(o), byref(hm), byref(ms))
+            out.append((_lib.K_NAMES[k.value], o.value, hm.value, ms.value))
+        return out
 
     def reset_stats(self) -> None:
         check(_lib.load().qsim_reset_stats(self._h))

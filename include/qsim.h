@@ -39,7 +39,7 @@ enum {
 };
 
 /* Gate kinds in a qsim_circuit. */
-enum { QSIM_GATE_U1 = 1, QSIM_GATE_CX = 2, QSIM_GATE_U2 = 3 };
+enum { QSIM_GATE_U1 = 1, QSIM_GATE_CX = 2, QSIM_GATE_U2 = 3, QSIM_GATE_U3 = 4 /* scheduler output only */ };
 
 /* Options for qsim_set_option. */
 enum {
@@ -52,11 +52,12 @@ enum {
      *      done with a full grid)                   [default]                                        */
     QSIM_OPT_FUSE = 1,
     QSIM_OPT_PROFILE = 2,      /* 1: bracket every launch with HIP events on the engine's stream */
-    QSIM_OPT_TILE_BITS = 3,    /* log2 amplitudes per LDS tile for level 3 (8..13, default 11) */
-    QSIM_OPT_TILE_LOW_BITS = 4,/* contiguous low index bits always inside a tile (default 6 -> 1 KiB runs) */
+    QSIM_OPT_TILE_BITS = 3,    /* log2 amplitudes per LDS tile for level 3 (8..13, default 12 = 64 KiB) */
+    QSIM_OPT_TILE_LOW_BITS = 4,/* contiguous low index bits always inside a tile (2..11, default 4 -> 256-B runs, 8 free high-qubit slots) */
     QSIM_OPT_MAX_PENDING = 5,  /* queued gates that force a flush (default 1<<16) */
-    QSIM_OPT_TILE_MAX_OPS = 6, /* upper bound on fused blocks per tile pass (default 24) */
-    QSIM_OPT_GRID_CAP = 7      /* 0: one workgroup per tile; >0: persistent grid of that many workgroups */
+    QSIM_OPT_TILE_MAX_OPS = 6, /* upper bound on fused blocks per tile pass (default 32) */
+    QSIM_OPT_GRID_CAP = 7,     /* 0: one workgroup per work tile; >0: at most that many workgroups (grid-stride loop) */
+    QSIM_OPT_TILE_THREADS = 8  /* threads per tile workgroup: 0 auto (256 below 2^12 amplitudes, else 512), 256, 512, 1024 */
 };
 
 /* Kernel classes reported by qsim_get_stats. */
@@ -128,6 +129,10 @@ int qsim_scale(qsim_state *s, double re, double im);
 
 int qsim_get_stats(qsim_state *s, qsim_stats *out); /* waits for outstanding profile events */
 int qsim_reset_stats(qsim_state *s);
+/* Per-launch record (QSIM_OPT_PROFILE=1) since the last qsim_reset_stats: returns the number of records and,
+ * for 0 <= index < count, fills the kernel class, the fused blocks in that launch, the tile's high-qubit
+ * mask and the HIP-event time. */
+long qsim_launch_log(qsim_state *s, long index, int *kernel_class, int *n_ops, uint64_t *high_mask, double *ms);
 
 /* ---- circuits: the tokenizer of compute_state_vector (quantum_simulator.c:115-254) ---------------- */
 /* Parses the OPENQASM-3 subset of quantum_simulator.c (two header statements, `qubit[n] q;` or
@@ -157,12 +162,12 @@ int qsim_gate_matrix(const char *token, double *U);
 /* Runs the fusion scheduler on a circuit and reports launches and algorithmic bytes per kernel class
  * for a state of num_q qubits at the given fuse level.  Used by tests and by the planner. */
 int qsim_plan_circuit(const qsim_circuit *c, int fuse, int tile_bits, int tile_low_bits, qsim_stats *out);
-/* Same scheduler, op by op: calls `cb` for every fused block in launch order with the pass it belongs to,
- * the kernel class of that pass, the block kind (QSIM_GATE_U1 / _CX / _U2), its qubits and its matrix
- * (8 or 32 doubles; NULL for CX).  Lets a CPU test replay the schedule with numpy and compare it with
- * the unfused circuit. */
-typedef void (*qsim_sched_cb)(void *user, int pass, int kernel_class, int kind, int q0, int q1, const double *U,
-                              int gates_folded);
+/* Same scheduler, op by op: calls `cb` for every fused block in launch order with the pass it belongs to, the
+ * kernel class of that pass, the block kind (QSIM_GATE_U1 / _CX / _U2 / _U3), its qubits (most significant
+ * first; CX: control, target) and its matrix (2^nq x 2^nq complex, row-major; NULL for CX).  Lets a CPU test
+ * replay the schedule with numpy and compare it with the unfused circuit. */
+typedef void (*qsim_sched_cb)(void *user, int pass, int kernel_class, int kind, const int *qubits, int nq,
+                              const double *U, int gates_folded);
 int qsim_schedule_circuit(const qsim_circuit *c, int fuse, int tile_bits, int tile_low_bits, int tile_max_ops,
                           qsim_sched_cb cb, void *user);
 

@@ -24,17 +24,26 @@ def np_apply_cx(state, n, control, target):
     return state[src]
 
 
+def np_apply_kq(state, n, U, qubits):
+    """k-qubit unitary, `qubits` most significant first (matrix index bits in that order)."""
+    k = len(qubits)
+    t = state.reshape([2] * n)  # axis a <-> qubit n-1-a
+    axes = [n - 1 - q for q in qubits]
+    M = np.asarray(U, dtype=np.complex128).reshape([2] * (2 * k))
+    out = np.tensordot(M, t, axes=(list(range(k, 2 * k)), axes))  # new axes 0..k-1 = the gate's output indices
+    out = np.moveaxis(out, list(range(k)), axes)
+    return np.ascontiguousarray(out).reshape(-1)
+
+
 def replay_schedule(n, sched):
     """Applies Circuit.schedule() output to |0..0> with numpy."""
     s = np.zeros(1 << n, dtype=np.complex128)
     s[0] = 1
-    for _pass, _k, kind, q0, q1, m, _folded in sched:
-        if kind == "u1":
-            s = np_apply_1q(s, n, m, q0)
-        elif kind == "cx":
-            s = np_apply_cx(s, n, q0, q1)
+    for _pass, _k, kind, qs, m, _folded in sched:
+        if kind == "cx":
+            s = np_apply_cx(s, n, qs[0], qs[1])
         else:
-            s = np_apply_2q(s, n, m, q0, q1)
+            s = np_apply_kq(s, n, m, qs)
     return s
 
 

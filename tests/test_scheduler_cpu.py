@@ -103,14 +103,14 @@ def test_schedule_replay_equals_oracle(oracle, tmp_path, fuse, n, depth, seed, v
     sched = c.schedule(fuse=fuse, tile_bits=8, tile_low_bits=4, tile_max_ops=6)
     got = replay_schedule(n, sched)
     assert np.max(np.abs(got - want)) < TOL
-    assert sum(s[6] for s in sched) <= depth  # folded gate counts never exceed the input
+    assert sum(s[5] for s in sched) <= depth  # folded gate counts never exceed the input
 
 
 def test_schedule_counts_every_gate_once_at_level0(tmp_path):
     gates = circuits.random_gates(7, 200, 9, "all")
     c = Circuit.from_gates(7, gates)
     sched = c.schedule(fuse=0)
-    assert len(sched) == 200 and all(s[6] == 1 for s in sched)
+    assert len(sched) == 200 and all(s[5] == 1 for s in sched)
     assert [s[2] for s in sched] == ["cx" if g[0] == "cx" else "u1" for g in gates]
 
 
@@ -118,10 +118,10 @@ def test_level2_pairs_follow_reference_example():
     """h q0; cx q0,q1 folds into ONE 4x4 = CX·(I⊗H) (the case A of quantum_simulator_4x4.cu:336-349)."""
     c = Circuit.from_text('OPENQASM 3.0;\ninclude "stdgates.inc";\nqubit q[2];\nh q[0];\ncx q[0], q[1];\n')
     sched = c.schedule(fuse=2)
-    assert len(sched) == 1 and sched[0][2] == "u2" and sched[0][3:5] == (1, 0) and sched[0][6] == 2
+    assert len(sched) == 1 and sched[0][2] == "u2" and sched[0][3] == (1, 0) and sched[0][5] == 2
     H = gate_matrix("h")
     CX_ctrl_lo = np.array([[1, 0, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0], [0, 1, 0, 0]], dtype=complex)
-    assert np.allclose(sched[0][5], CX_ctrl_lo @ np.kron(np.eye(2), H), atol=0, rtol=0)
+    assert np.allclose(sched[0][4], CX_ctrl_lo @ np.kron(np.eye(2), H), atol=0, rtol=0)
 
 
 def test_exact_identity_is_dropped_but_near_identity_is_kept():
@@ -132,7 +132,7 @@ def test_exact_identity_is_dropped_but_near_identity_is_kept():
     eps = np.array([[1, 0], [0, np.exp(1e-4j)]])  # would pass the reference's 1e-3 isIdentity test (B9)
     c.append_1q(eps, 2)
     sched = c.schedule(fuse=2)
-    assert len(sched) == 1 and sched[0][3] == 2 and np.array_equal(sched[0][5], eps)
+    assert len(sched) == 1 and sched[0][3] == (2,) and np.array_equal(sched[0][4], eps)
 
 
 def test_generic_two_qubit_gates_and_blocking(oracle):
@@ -177,5 +177,6 @@ def test_tile_passes_respect_geometry_limits():
     for ops in by_pass.values():
         assert len(ops) <= 5
         if ops[0][1] == "tile":
-            high = {q for o in ops for q in (o[3], o[4]) if q >= 6}
+            high = {q for o in ops for q in o[3] if q >= 6}
             assert len(high) <= 4
+            assert all(len(o[3]) <= 3 and (o[4] != 0).sum(axis=1).max() <= (4 if len(o[3]) == 3 else 4) for o in ops)

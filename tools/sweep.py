@@ -74,6 +74,33 @@ def main():
                 ms, gbs, k = timed(sim, lambda: sim.pack_bits(bits, dst.data_ptr()), 5)
                 print(f"pack     {str(bits):14s} {ms:9.3f} ms  {gbs:8.1f} GB/s  {k}", flush=True)
             del dst
+    if "tileops" in what:
+        # cost of one fused block inside a tile pass, by sparsity class: chains of 2q gates on overlapping pairs of
+        # five high qubits (each closes the previous cluster), all inside ONE tile pass
+        pairs = [(n - 1, n - 2), (n - 2, n - 3), (n - 3, n - 4), (n - 4, n - 5), (n - 1, n - 5), (n - 1, n - 3), (n - 2, n - 4),
+                 (n - 3, n - 5), (n - 1, n - 4), (n - 2, n - 5)]
+        ph = np.exp(1j * np.array([0.1, 0.7, 1.3, 2.1]))
+        mono = np.zeros((4, 4), dtype=complex)
+        for r, c in enumerate((1, 0, 3, 2)):
+            mono[r, c] = ph[r]
+        cxm = np.eye(4)[[0, 1, 3, 2]].astype(complex)
+        pair = cxm @ np.kron(np.diag([1, np.exp(0.3j)]), H)
+        for tb, tl in ((11, 6), (12, 6), (12, 7), (11, 5), (10, 5)):
+            for label, M in (("dense", q4), ("pair", pair), ("mono", mono), ("cx", cxm)):
+                for nops in (1, 4, 8, 16):
+                    with Simulator(n, fuse=3, profile=True, tile_bits=tb, tile_low_bits=tl, tile_max_ops=64, grid_cap=a.grid_cap) as sim:
+                        for q in range(n):
+                            sim.apply_1q(H, q)
+                        sim.sync()
+
+                        def body():
+                            for j in range(nops):
+                                hi, lo = pairs[j % len(pairs)]
+                                sim.apply_2q(M, hi, lo)
+                            sim.flush()
+                        ms, gbs, k = timed(sim, body, 5)
+                        st = sim.stats()
+                        print(f"tileops B={tb} L={tl} {label:5s} ops={nops:2d}: {ms:8.3f} ms {gbs:8.1f} GB/s launches/iter={st['launches']/5:.1f}", flush=True)
     if "tile" in what:
         # tile kernel with k dense 4x4 ops on fixed high qubits, for several geometries
         for tb, tl in ((12, 7), (12, 6), (11, 7), (11, 6), (13, 7), (10, 6)):

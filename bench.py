@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--grid-cap", type=int, default=None)
     ap.add_argument("--probe", type=int, default=None, metavar="Q",
                     help="single-qubit roofline probe instead of the random circuit: `depth` h gates on qubit Q, fusion off")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="with --gpus 1: still go through torch.distributed + ShardedSimulator (rehearsal of the N>1 code path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -144,9 +146,11 @@ def main():
                               ("tile_max_ops", args.tile_max_ops), ("grid_cap", args.grid_cap)) if v is not None}
 
     dist = None
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         from gpu_quantum_simulator_amd.distributed import ShardedSimulator
         sim = ShardedSimulator(n, gates, device=local_rank, fuse=fuse, profile=True, **opts)
@@ -184,6 +188,26 @@ def main():
 
     stats = sim.stats()
     norm2 = sim.norm2()
+
+    # north_star target "single-qubit gate apply at n=30": a short dense-1q probe on the same (now dense) state
+    probe = None
+    if dist is None and args.probe is None and n >= 8:
+        from gpu_quantum_simulator_amd import _lib as _qlib, gate_matrix
+        H = gate_matrix("h")
+        sim.set_option(_qlib.OPT_FUSE, 0)  # one launch per gate on the live (dense, random) state; H^6 = I
+        probe = {}
+        for q in sorted({0, min(12, n - 1), n - 1}):
+            sim.sync()
+            sim.reset_stats()
+            for _ in range(6):
+                sim.apply_1q(H, q)
+            sim.sync()
+            k = {kk: vv for kk, vv in sim.stats()["kernels"].items() if vv["launches"] and kk != "init"}
+            name = next(iter(k))
+            gbs = k[name]["bytes"] / (k[name]["ms"] * 1e-3) / 1e9
+            probe[f"q{q}"] = {"kernel": name, "achieved": gbs, "frac": gbs / HBM_PEAK_GBPS, "avg_launch_ms": k[name]["ms"] / 6}
+        sim.set_option(_qlib.OPT_FUSE, fuse)
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = args.depth * args.steps / elapsed
@@ -211,8 +235,9 @@ def main():
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in stats["kernels"].items() if v["launches"]},
             "norm2": norm2,
             "roofline": roof,
+            "roofline_1q_probe": probe,
         }
-        if world > 1:
+        if dist is not None:
             xs = sim.exchange_seconds / args.steps
             xb = sim.exchange_bytes / args.steps
             out["exchange"] = {"per_step": sim.plan.exchanges, "qubits_swapped": [len(s[1]) for s in sim.plan.steps if s[0] == "exchange"],

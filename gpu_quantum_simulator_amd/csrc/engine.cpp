@@ -361,19 +361,26 @@ static bool to_tile_op(const TileGeom &g, const FusedOp &op, TileOp &t) {
     const int T = maxnnz <= 1 ? 1 : maxnnz <= 2 ? 2 : 4;
     t.kind = TOP_SP;
     t.terms = T;
+    auto slot_off = [&](int code) { // LDS index offset of a slot code: bit a of the code sits at tile-local bit b[a]
+        uint32_t o = 0;
+        for (int a = 0; a < k; a++) o |= (uint32_t)((code >> a) & 1) << t.b[a];
+        return o;
+    };
     for (int r = 0; r < D; r++) {
+        t.rowoffw[r >> 1] |= slot_off(r) << (16 * (r & 1));
         int j = 0;
         for (int c = 0; c < D; c++)
             if (nz(r, c)) {
                 const int e = r * T + j++;
-                t.colw[e >> 2] |= (uint32_t)c << (8 * (e & 3));
+                t.offw[e >> 1] |= slot_off(c) << (16 * (e & 1));
                 t.re[e] = op.m[D * r + c].real();
                 t.im[e] = op.m[D * r + c].imag();
+                if (is1(op.m[D * r + c])) t.unit |= 1u << e;
             }
         if (j == 1 && nz(r, r) && is1(op.m[D * r + r])) t.meta |= 1 << r; // identity row: no traffic at all
         for (; j < T; j++) { // pad with a zero coefficient on the row's own slot
             const int e = r * T + j;
-            t.colw[e >> 2] |= (uint32_t)r << (8 * (e & 3));
+            t.offw[e >> 1] |= slot_off(r) << (16 * (e & 1));
         }
     }
     return true;

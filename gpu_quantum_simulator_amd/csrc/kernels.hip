@@ -279,13 +279,7 @@ __device__ __forceinline__ void tile_op_sparse(amp_t *lds, ConstOps ops, int oi,
     constexpr int GPT = NG >= (uint32_t)THREADS ? NG / THREADS : 1;  // groups per thread
     constexpr bool FULL = NG >= (uint32_t)THREADS && NG % THREADS == 0;
     const uint32_t b0 = (uint32_t)ops[oi].b[0], b1 = (uint32_t)ops[oi].b[1], b2 = (uint32_t)ops[oi].b[2];
-    const uint32_t skip = (uint32_t)ops[oi].meta;
-    auto slot = [&](uint32_t c) -> uint32_t { // wave-uniform: LDS index offset of slot code c
-        uint32_t o = (c & 1u) << b0;
-        if (K >= 2) o |= ((c >> 1) & 1u) << b1;
-        if (K >= 3) o |= ((c >> 2) & 1u) << b2;
-        return o;
-    };
+    const uint32_t skip = (uint32_t)ops[oi].meta, unit = ops[oi].unit;
     uint32_t base[GPT];
 #pragma unroll
     for (int g = 0; g < GPT; g++) {
@@ -297,24 +291,33 @@ __device__ __forceinline__ void tile_op_sparse(amp_t *lds, ConstOps ops, int oi,
     amp_t y[GPT][R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        if ((skip >> r) & 1u) continue;
+        if ((skip >> r) & 1u) continue; // wave-uniform
 #pragma unroll
         for (int j = 0; j < T; j++) {
             const int e = r * T + j;
-            const uint32_t off = slot((ops[oi].colw[e >> 2] >> (8 * (e & 3))) & 0xffu);
-            const double cr = ops[oi].re[e], ci = ops[oi].im[e];
+            const uint32_t off = (ops[oi].offw[e >> 1] >> (16 * (e & 1))) & 0xffffu; // wave-uniform
+            if ((unit >> e) & 1u) { // coefficient exactly 1: move / add, no multiply
 #pragma unroll
-            for (int g = 0; g < GPT; g++)
-                if (FULL || tid + g * THREADS < NG) {
-                    const amp_t x = lds[base[g] | off];
-                    y[g][r] = j == 0 ? cmul(x, cr, ci) : cfma(x, cr, ci, y[g][r]);
-                }
+                for (int g = 0; g < GPT; g++)
+                    if (FULL || tid + g * THREADS < NG) {
+                        const amp_t x = lds[base[g] | off];
+                        y[g][r] = j == 0 ? x : y[g][r] + x;
+                    }
+            } else {
+                const double cr = ops[oi].re[e], ci = ops[oi].im[e];
+#pragma unroll
+                for (int g = 0; g < GPT; g++)
+                    if (FULL || tid + g * THREADS < NG) {
+                        const amp_t x = lds[base[g] | off];
+                        y[g][r] = j == 0 ? cmul(x, cr, ci) : cfma(x, cr, ci, y[g][r]);
+                    }
+            }
         }
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
         if ((skip >> r) & 1u) continue;
-        const uint32_t off = slot((uint32_t)r);
+        const uint32_t off = (ops[oi].rowoffw[r >> 1] >> (16 * (r & 1))) & 0xffffu;
 #pragma unroll
         for (int g = 0; g < GPT; g++)
             if (FULL || tid + g * THREADS < NG) lds[base[g] | off] = y[g][r];

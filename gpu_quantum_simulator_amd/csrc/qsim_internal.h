@@ -20,8 +20,10 @@ struct M4 { double re[16], im[16]; };
 //   TOP_DIAG1  diag(d0, d1) on b[0]                   re/im[0..1]; meta bit 0: d0 == 1 (only the bit=1 half moves)
 //   TOP_G2     dense 4x4 on (b[1], b[0])              re/im[0..15] row-major, operands held in registers
 //   TOP_SP     sparse 2^k x 2^k block, k = nq in {2,3}: every row r has `terms` (1, 2 or 4) entries
-//              y[r] = sum_j coef[r*terms + j] * x[col[r*terms + j]], operands fetched straight from their LDS slots
-//              (wave-uniform offsets); rows with meta bit r set are untouched (identity row) and cost nothing.
+//              y[r] = sum_j coef[r*terms + j] * x[slot_j], operands fetched straight from their LDS slots: the host
+//              stores each entry's slot as a ready LDS index offset (wave-uniform), rows with meta bit r set are
+//              untouched (identity row) and cost nothing, entries with their `unit` bit set have coefficient
+//              exactly 1 and skip the multiply (bare CX structure).
 //              Most fused clusters of Clifford+T-like circuits are permutations times phases or two independent
 //              2x2 blocks, and so are products of neighbouring ones on <= 3 qubits (Scheduler::merge_sparse).
 enum : int32_t { TOP_G1 = 1, TOP_G2 = 2, TOP_DIAG1 = 3, TOP_SP = 4 };
@@ -31,12 +33,13 @@ struct TileOp {
     int32_t b[3];     // tile-local bits, ascending
     int32_t terms;    // TOP_SP: entries per row (1, 2, 4)
     int32_t meta;     // see above
-    int32_t pad;
-    uint32_t colw[8]; // TOP_SP: slot code of entry e in byte e%4 of colw[e/4]
+    uint32_t unit;    // TOP_SP: bit e set when coefficient e is exactly 1
+    uint32_t offw[16];   // TOP_SP: LDS index offset (in amplitudes) of entry e in half e%2 of offw[e/2]
+    uint32_t rowoffw[4]; // TOP_SP: LDS index offset of row r in half r%2 of rowoffw[r/2]
     double re[32];
     double im[32];
 };
-static_assert(sizeof(TileOp) == 576, "TileOp layout is shared with the device");
+static_assert(sizeof(TileOp) == 624, "TileOp layout is shared with the device");
 
 constexpr int kMaxTileHigh = 10; // high (non-contiguous) qubits per tile
 struct TileGeom {

@@ -253,23 +253,36 @@ void Scheduler::build_passes(std::vector<Pass> &out) {
     while (first < m) {
         if (done[first]) { first++; continue; }
         group.clear();
-        uint64_t hset = 0, blocked = 0;
+        uint64_t hset = 0;
         const size_t end = std::min(m, first + (size_t)cfg_.window);
-        for (size_t i = first; i < end; i++) {
-            if (done[i]) continue;
-            const FusedOp &op = closed_[i];
-            const uint64_t qmask = op.qmask();
-            if (qmask & blocked) { blocked |= qmask; continue; }
-            const uint64_t need = qmask & ~lowmask & ~hset;
-            if (__builtin_popcountll(hset) + __builtin_popcountll(need) <= kmax &&
-                (int)group.size() < cfg_.tile_max_ops) {
-                group.push_back(op);
-                hset |= need;
-                done[i] = 1;
-            } else {
-                blocked |= qmask;
+        // Grow the pass one block at a time, always taking the runnable block that needs the FEWEST new high-qubit
+        // slots (blocks that fit the qubits already chosen are free), earliest first among equals.  A block is
+        // runnable when no earlier pending block shares a qubit with it, directly or through a chain of pending
+        // blocks (those qubits are "blocked"), so emitting blocks in the order they are picked respects every
+        // dependency.
+        while ((int)group.size() < cfg_.tile_max_ops) {
+            uint64_t blocked = 0;
+            long best = -1;
+            int best_need = 1 << 30;
+            for (size_t i = first; i < end; i++) {
+                if (done[i]) continue;
+                const uint64_t qmask = closed_[i].qmask();
+                if (!(qmask & blocked)) {
+                    const int need = __builtin_popcountll(qmask & ~lowmask & ~hset);
+                    if (__builtin_popcountll(hset) + need <= kmax && need < best_need) {
+                        best = (long)i;
+                        best_need = need;
+                        if (need == 0) break;
+                    }
+                }
+                blocked |= qmask; // not taken (yet): everything later on these qubits has to wait
+                if (blocked == all) break;
             }
-            if (blocked == all) break;
+            if (best < 0) break;
+            const FusedOp &op = closed_[(size_t)best];
+            group.push_back(op);
+            hset |= op.qmask() & ~lowmask;
+            done[(size_t)best] = 1;
         }
         if (group.empty()) { // cannot happen while kmax >= 2; keep the scheduler total anyway
             single_op_pass(closed_[first], out);

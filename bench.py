@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--grid-cap", type=int, default=None)
     ap.add_argument("--probe", type=int, default=None, metavar="Q",
                     help="single-qubit roofline probe instead of the random circuit: `depth` h gates on qubit Q, fusion off")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: the same n on every N (default, the metric is quoted at n=30); weak: n = qubits + log2(N)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="with --gpus 1: still go through torch.distributed + ShardedSimulator (rehearsal of the N>1 code path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -132,7 +134,7 @@ def main():
 
     from gpu_quantum_simulator_amd import Circuit, Simulator, circuits
 
-    n = args.qubits
+    n = args.qubits + (int(round(__import__("math").log2(world))) if args.scaling == "weak" else 0)
     seed = args.seed if args.seed is not None else 20240117 + n
     if args.probe is not None:
         gates = circuits.probe_gates(n, args.probe, args.depth)
@@ -227,7 +229,7 @@ def main():
         out = {
             "metric": "gate-applies/sec", "value": value, "unit": "gate-applies/s", "n_gpus": args.gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "qubits": n, "gate_statements": args.depth, "fuse": fuse,
                        "state_bytes": 16 * (1 << n), "parallelism": f"shard{args.gpus}", **opts},
             "hbm_gbps_all_kernels": stats["algorithmic_bytes"] / (total_kernel_ms * 1e-3) / 1e9 if total_kernel_ms else None,

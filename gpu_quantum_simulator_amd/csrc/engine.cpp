@@ -64,7 +64,7 @@ struct qsim_state {
     double2 *amps = nullptr;
     bool owns = false;
     // options
-    int fuse = 3, profile = 0, tile_bits = 12, tile_low_bits = 4, tile_max_ops = 32, grid_cap = 0, tile_threads = 0;
+    int fuse = 3, profile = 0, tile_bits = 12, tile_low_bits = 3, tile_max_ops = 32, grid_cap = 0, tile_threads = 0, tile_pad_from = 10;
     long max_pending = 1L << 16;
     // queue
     std::vector<QueuedGate> queue;
@@ -169,6 +169,9 @@ extern "C" int qsim_set_option(qsim_state *s, int option, long value) {
         if (value < 0) return fail(QSIM_ERR_ARG, "grid_cap must be >= 0");
         s->grid_cap = (int)value;
         break;
+    case QSIM_OPT_TILE_PAD_FROM:
+        s->tile_pad_from = (int)value;
+        break;
     case QSIM_OPT_TILE_THREADS:
         if (value != 0 && value != 256 && value != 512 && value != 1024)
             return fail(QSIM_ERR_ARG, "tile_threads must be 0 (auto), 256, 512 or 1024");
@@ -190,6 +193,7 @@ extern "C" long qsim_get_option(const qsim_state *s, int option) {
     case QSIM_OPT_TILE_MAX_OPS: return s->tile_max_ops;
     case QSIM_OPT_GRID_CAP: return s->grid_cap;
     case QSIM_OPT_TILE_THREADS: return s->tile_threads;
+    case QSIM_OPT_TILE_PAD_FROM: return s->tile_pad_from;
     default: return -1;
     }
 }
@@ -299,8 +303,9 @@ extern "C" int qsim_apply_2q(qsim_state *s, const double *U, int q_hi, int q_lo)
 }
 
 // ---- scheduling + launch -------------------------------------------------------------------------------
-static SchedConfig sched_config(int n, int fuse, int tile_bits, int tile_low_bits, int tile_max_ops) {
+static SchedConfig sched_config(int n, int fuse, int tile_bits, int tile_low_bits, int tile_max_ops, int pad_from = 10) {
     SchedConfig c;
+    c.pad_from = pad_from;
     c.n = n; c.fuse = fuse; c.tile_bits = tile_bits; c.tile_low_bits = tile_low_bits; c.tile_max_ops = tile_max_ops;
     return c;
 }
@@ -367,21 +372,17 @@ static bool to_tile_op(const TileGeom &g, const FusedOp &op, TileOp &t) {
         return o;
     };
     for (int r = 0; r < D; r++) {
-        t.rowoffw[r >> 1] |= slot_off(r) << (16 * (r & 1));
+        t.rowoff[r] = slot_off(r) * 16u;
         int j = 0;
         for (int c = 0; c < D; c++)
             if (nz(r, c)) {
                 const int e = r * T + j++;
-                t.offw[e >> 1] |= slot_off(c) << (16 * (e & 1));
+                t.off[e] = slot_off(c) * 16u;
                 t.re[e] = op.m[D * r + c].real();
                 t.im[e] = op.m[D * r + c].imag();
-                if (is1(op.m[D * r + c])) t.unit |= 1u << e;
             }
         if (j == 1 && nz(r, r) && is1(op.m[D * r + r])) t.meta |= 1 << r; // identity row: no traffic at all
-        for (; j < T; j++) { // pad with a zero coefficient on the row's own slot
-            const int e = r * T + j;
-            t.offw[e >> 1] |= slot_off(r) << (16 * (e & 1));
-        }
+        for (; j < T; j++) t.off[r * T + j] = slot_off(r) * 16u; // pad: zero coefficient on the row's own slot
     }
     return true;
 }
@@ -453,7 +454,7 @@ extern "C" int qsim_flush(qsim_state *s) {
     if (s->tile_bits - s->tile_low_bits < 2 || s->tile_bits - s->tile_low_bits > kMaxTileHigh)
         return fail(QSIM_ERR_ARG, "tile_bits - tile_low_bits must be in 2..%d", kMaxTileHigh);
     HIP_TRY(hipSetDevice(s->device));
-    Scheduler sched(sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops));
+    Scheduler sched(sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from));
     for (const QueuedGate &g : s->queue) {
         if (g.kind == QSIM_GATE_U1) sched.add_1q(g.m, g.q0);
         else if (g.kind == QSIM_GATE_CX) sched.add_cx(g.q0, g.q1);

@@ -279,48 +279,51 @@ __device__ __forceinline__ void tile_op_sparse(amp_t *lds, ConstOps ops, int oi,
     constexpr int GPT = NG >= (uint32_t)THREADS ? NG / THREADS : 1;  // groups per thread
     constexpr bool FULL = NG >= (uint32_t)THREADS && NG % THREADS == 0;
     const uint32_t b0 = (uint32_t)ops[oi].b[0], b1 = (uint32_t)ops[oi].b[1], b2 = (uint32_t)ops[oi].b[2];
-    const uint32_t skip = (uint32_t)ops[oi].meta, unit = ops[oi].unit;
-    uint32_t base[GPT];
+    const uint32_t skip = (uint32_t)ops[oi].meta;
+    unsigned char *ldsb = reinterpret_cast<unsigned char *>(lds);
+    uint32_t base[GPT]; // BYTE address of the group's slot 0
 #pragma unroll
     for (int g = 0; g < GPT; g++) {
         uint32_t x = ins0(tid + g * THREADS, ~((1u << b0) - 1u));
         if (K >= 2) x = ins0(x, ~((1u << b1) - 1u));
         if (K >= 3) x = ins0(x, ~((1u << b2) - 1u));
-        base[g] = x;
+        base[g] = x << 4;
     }
     amp_t y[GPT][R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        if ((skip >> r) & 1u) continue; // wave-uniform
+        if ((skip >> r) & 1u) continue; // wave-uniform; everything below is straight-line per row
+        uint32_t off[T];
+        double cr[T], ci[T];
 #pragma unroll
         for (int j = 0; j < T; j++) {
             const int e = r * T + j;
-            const uint32_t off = (ops[oi].offw[e >> 1] >> (16 * (e & 1))) & 0xffffu; // wave-uniform
-            if ((unit >> e) & 1u) { // coefficient exactly 1: move / add, no multiply
-#pragma unroll
-                for (int g = 0; g < GPT; g++)
-                    if (FULL || tid + g * THREADS < NG) {
-                        const amp_t x = lds[base[g] | off];
-                        y[g][r] = j == 0 ? x : y[g][r] + x;
-                    }
-            } else {
-                const double cr = ops[oi].re[e], ci = ops[oi].im[e];
-#pragma unroll
-                for (int g = 0; g < GPT; g++)
-                    if (FULL || tid + g * THREADS < NG) {
-                        const amp_t x = lds[base[g] | off];
-                        y[g][r] = j == 0 ? cmul(x, cr, ci) : cfma(x, cr, ci, y[g][r]);
-                    }
-            }
+            off[j] = ops[oi].off[e];
+            cr[j] = ops[oi].re[e];
+            ci[j] = ops[oi].im[e];
         }
+        amp_t x[GPT][T];
+#pragma unroll
+        for (int g = 0; g < GPT; g++)
+#pragma unroll
+            for (int j = 0; j < T; j++)
+                if (FULL || tid + g * THREADS < NG) x[g][j] = *reinterpret_cast<amp_t *>(ldsb + (base[g] | off[j])); // T reads in flight
+#pragma unroll
+        for (int g = 0; g < GPT; g++)
+            if (FULL || tid + g * THREADS < NG) {
+                amp_t acc = cmul(x[g][0], cr[0], ci[0]);
+#pragma unroll
+                for (int j = 1; j < T; j++) acc = cfma(x[g][j], cr[j], ci[j], acc);
+                y[g][r] = acc;
+            }
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
         if ((skip >> r) & 1u) continue;
-        const uint32_t off = (ops[oi].rowoffw[r >> 1] >> (16 * (r & 1))) & 0xffffu;
+        const uint32_t off = ops[oi].rowoff[r];
 #pragma unroll
         for (int g = 0; g < GPT; g++)
-            if (FULL || tid + g * THREADS < NG) lds[base[g] | off] = y[g][r];
+            if (FULL || tid + g * THREADS < NG) *reinterpret_cast<amp_t *>(ldsb + (base[g] | off)) = y[g][r];
     }
 }
 
@@ -328,7 +331,7 @@ __device__ __forceinline__ void tile_op_sparse(amp_t *lds, ConstOps ops, int oi,
 // reads of an op are issued before its arithmetic, all writes after, and there is no loop bookkeeping.
 template <int B, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_tile(amp_t *__restrict__ v, TileDev g, const TileOp *__restrict__ ops_g,
-                                                  int n_ops, uint64_t ntiles) {
+                                                  int n_ops, uint64_t ntiles, int tiles_per_wg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     amp_t *lds = reinterpret_cast<amp_t *>(smem);
     constexpr uint32_t E = 1u << B;
@@ -347,26 +350,36 @@ __global__ __launch_bounds__(THREADS) void k_tile(amp_t *__restrict__ v, TileDev
     for (uint32_t j = tid; j < (1u << H); j += THREADS) hoff[j] = deposit(j, g.high_mask);
     __syncthreads();
 
-    // One tile per workgroup (a grid-stride loop only when the grid is capped).  Measured alternatives that lost:
-    // a persistent grid that prefetches the next tile into registers during the op phase (even with loader /
-    // storer wave roles so that s_waitcnt vmcnt stays exact): the extra 64 VGPRs halve the resident workgroups
-    // and the chip is already queue-limited on HBM, 11.4 vs 7.8 ms per pass at n = 30.
-    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // A workgroup walks `tiles_per_wg` consecutive tiles.  While tile j is being processed in LDS, the loads of
+    // tile j+1 are already in flight into registers (APT amplitudes per lane), which keeps bytes in flight during
+    // the op phase: the kernel is latency-bound (bandwidth follows the number of workgroups currently in their
+    // memory phase), and LDS capacity caps the resident tiles at two per CU.
+    // vmcnt counts loads and stores together, in issue order, and the compiler merges its counter state at the
+    // loop head: the first iteration is peeled so that BOTH ways into the loop carry [prefetch loads][stores of
+    // the previous tile] — the wait it inserts before the prefetched registers are used is then vmcnt(#stores),
+    // i.e. exact, instead of draining the previous tile's stores as well.  The prefetch is unconditional (the last
+    // iteration re-fetches its own tile and ignores it) to keep every path identical.
+    const uint64_t first_tile = (uint64_t)blockIdx.x * (uint64_t)tiles_per_wg;
+    if (first_tile >= ntiles) return;
+    const int cnt = (int)((ntiles - first_tile) < (uint64_t)tiles_per_wg ? (ntiles - first_tile) : (uint64_t)tiles_per_wg);
+    amp_t pf[APT];
+    auto fetch = [&](uint64_t t) {
+        const uint64_t tb = deposit(t, outer_mask); // wave-uniform
+#pragma unroll
+        for (int k = 0; k < APT; k++) {
+            const uint32_t e = tid + k * THREADS;
+            pf[k] = (FULL || e < E) ? v[tb | hoff[e >> L] | (uint64_t)(e & lowmask)] : amp_t{0.0, 0.0};
+        }
+    };
+    auto process = [&](uint64_t tile, uint64_t next) {
         const uint64_t base = deposit(tile, outer_mask); // wave-uniform
-        {   // stage in: every load of the thread in flight before the first LDS store
-            amp_t r[APT];
 #pragma unroll
-            for (int k = 0; k < APT; k++) {
-                const uint32_t e = tid + k * THREADS;
-                r[k] = (FULL || e < E) ? v[base | hoff[e >> L] | (uint64_t)(e & lowmask)] : amp_t{0.0, 0.0};
-            }
-#pragma unroll
-            for (int k = 0; k < APT; k++) {
-                const uint32_t e = tid + k * THREADS;
-                if (FULL || e < E) lds[e] = r[k];
-            }
+        for (int k = 0; k < APT; k++) {
+            const uint32_t e = tid + k * THREADS;
+            if (FULL || e < E) lds[e] = pf[k];
         }
         __syncthreads();
+        fetch(next);
 
         for (int oi = 0; oi < n_ops; oi++) {
             const int kind = ops[oi].kind;
@@ -460,7 +473,11 @@ __global__ __launch_bounds__(THREADS) void k_tile(amp_t *__restrict__ v, TileDev
             if (FULL || e < E) v[base | hoff[e >> L] | (uint64_t)(e & lowmask)] = lds[e];
         }
         __syncthreads();
-    }
+    };
+
+    fetch(first_tile);
+    process(first_tile, first_tile + (cnt > 1 ? 1 : 0)); // peeled
+    for (int j = 1; j < cnt; j++) process(first_tile + j, first_tile + (j + 1 < cnt ? j + 1 : j));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -623,8 +640,13 @@ static hipError_t launch_tile_t(const LaunchCfg &cfg, double2 *v, const TileGeom
     td.tile_bits = g.tile_bits; td.low_bits = g.low_bits; td.n_high = g.n_high; td.n = g.n;
     td.high_mask = 0;
     for (int j = 0; j < g.n_high; j++) td.high_mask |= 1ULL << g.high[j];
-    hipLaunchKernelGGL((k_tile<B, THREADS>), dim3(grid_for(cfg, ntiles)), dim3(THREADS), lds, cfg.stream, (amp_t *)v, td,
-                       d_ops, n_ops, ntiles);
+    // tiles per workgroup: enough to amortise the exposed first load, few enough to keep >= 8 workgroups per CU slot
+    int tpw = cfg.grid_cap > 0 ? (int)((ntiles + cfg.grid_cap - 1) / (uint64_t)cfg.grid_cap) : 8;
+    while (tpw > 1 && ntiles / (uint64_t)tpw < 4096) tpw >>= 1;
+    if (tpw < 1) tpw = 1;
+    const uint64_t grid = (ntiles + tpw - 1) / (uint64_t)tpw;
+    hipLaunchKernelGGL((k_tile<B, THREADS>), dim3((unsigned)grid), dim3(THREADS), lds, cfg.stream, (amp_t *)v, td, d_ops, n_ops,
+                       ntiles, tpw);
     return hipGetLastError();
 }
 

@@ -22,8 +22,9 @@ struct M4 { double re[16], im[16]; };
 //   TOP_SP     sparse 2^k x 2^k block, k = nq in {2,3}: every row r has `terms` (1, 2 or 4) entries
 //              y[r] = sum_j coef[r*terms + j] * x[slot_j], operands fetched straight from their LDS slots: the host
 //              stores each entry's slot as a ready LDS index offset (wave-uniform), rows with meta bit r set are
-//              untouched (identity row) and cost nothing, entries with their `unit` bit set have coefficient
-//              exactly 1 and skip the multiply (bare CX structure).
+//              untouched (identity row) and cost nothing.  (A per-entry "coefficient is exactly 1" shortcut was
+//              measured and dropped: its wave-uniform branches serialise the LDS reads and double the scalar
+//              instruction count.)
 //              Most fused clusters of Clifford+T-like circuits are permutations times phases or two independent
 //              2x2 blocks, and so are products of neighbouring ones on <= 3 qubits (Scheduler::merge_sparse).
 enum : int32_t { TOP_G1 = 1, TOP_G2 = 2, TOP_DIAG1 = 3, TOP_SP = 4 };
@@ -33,13 +34,13 @@ struct TileOp {
     int32_t b[3];     // tile-local bits, ascending
     int32_t terms;    // TOP_SP: entries per row (1, 2, 4)
     int32_t meta;     // see above
-    uint32_t unit;    // TOP_SP: bit e set when coefficient e is exactly 1
-    uint32_t offw[16];   // TOP_SP: LDS index offset (in amplitudes) of entry e in half e%2 of offw[e/2]
-    uint32_t rowoffw[4]; // TOP_SP: LDS index offset of row r in half r%2 of rowoffw[r/2]
+    uint32_t pad;
+    uint32_t off[32];    // TOP_SP: LDS BYTE offset of entry e's operand slot
+    uint32_t rowoff[8];  // TOP_SP: LDS BYTE offset of row r's slot
     double re[32];
     double im[32];
 };
-static_assert(sizeof(TileOp) == 624, "TileOp layout is shared with the device");
+static_assert(sizeof(TileOp) == 704, "TileOp layout is shared with the device");
 
 constexpr int kMaxTileHigh = 10; // high (non-contiguous) qubits per tile
 struct TileGeom {

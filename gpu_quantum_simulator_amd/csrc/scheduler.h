@@ -55,10 +55,11 @@ struct SchedConfig {
     int n = 0;
     int fuse = 3;
     int tile_bits = 12;
-    int tile_low_bits = 4;
+    int tile_low_bits = 3;
     int tile_max_ops = 32;
     int window = 4096; // clusters scanned ahead when grouping a pass
     int merge = 1;     // level 3: merge neighbouring blocks of a pass into sparse <=3-qubit blocks
+    int pad_from = 10; // first bit tried when unused tile slots are filled (below tile_low_bits: tile_low_bits)
 };
 
 class Scheduler {

@@ -291,6 +291,30 @@ class ShardedSimulator:
                 self.shard.compile(i, st[1])
         self.exchange_seconds = 0.0
         self.exchange_bytes = 0
+        self._warm_up_links()
+
+    def _warm_up_links(self):
+        """One tiny send/recv with every peer this rank will ever exchange with, so communicator set-up (RCCL builds
+        its point-to-point channels lazily) never lands inside a timed step."""
+        if self.world == 1:
+            return
+        import torch
+        dist, shard = self.dist, self.shard
+        dev = shard.state.device
+        peers = sorted({peer for st in self.plan.steps if st[0] == "exchange"
+                        for peer in peers_of(self.rank, st[1])[1] if peer != self.rank})
+        if peers:
+            tx = torch.zeros(8, dtype=torch.float64, device=dev)
+            rx = [torch.zeros(8, dtype=torch.float64, device=dev) for _ in peers]
+            ops = []
+            for i, peer in enumerate(peers):
+                ops.append(dist.P2POp(dist.isend, tx, peer))
+                ops.append(dist.P2POp(dist.irecv, rx[i], peer))
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        dist.barrier()
 
     def run_step(self):
         import time

@@ -101,12 +101,12 @@ class Circuit:
             return ("cx", q0.value, q1.value)
         return ("u2", q0.value, q1.value, u.view(np.complex128).reshape(4, 4).copy())
 
-    def plan(self, fuse: int = 3, tile_bits: int = 12, tile_low_bits: int = 4) -> dict:
+    def plan(self, fuse: int = 3, tile_bits: int = 12, tile_low_bits: int = 3) -> dict:
         st = QsimStats()
         check(_lib.load().qsim_plan_circuit(self._h, fuse, tile_bits, tile_low_bits, byref(st)))
         return st.as_dict()
 
-    def schedule(self, fuse: int = 3, tile_bits: int = 12, tile_low_bits: int = 4, tile_max_ops: int = 32) -> list:
+    def schedule(self, fuse: int = 3, tile_bits: int = 12, tile_low_bits: int = 3, tile_max_ops: int = 32) -> list:
         """Fused blocks in launch order: (pass, kernel_class, kind, qubits, matrix|None, gates_folded); kind is
         "u1" / "cx" / "u2" / "u3", qubits most significant first (cx: control, target)."""
         out = []
@@ -153,7 +153,8 @@ class Simulator:
             self.set_option(_lib.OPT_PROFILE, 1)
         names = {"tile_bits": _lib.OPT_TILE_BITS, "tile_low_bits": _lib.OPT_TILE_LOW_BITS,
                  "max_pending": _lib.OPT_MAX_PENDING, "tile_max_ops": _lib.OPT_TILE_MAX_OPS,
-                 "grid_cap": _lib.OPT_GRID_CAP, "tile_threads": _lib.OPT_TILE_THREADS}
+                 "grid_cap": _lib.OPT_GRID_CAP, "tile_threads": _lib.OPT_TILE_THREADS,
+                 "tile_pad_from": _lib.OPT_TILE_PAD_FROM}
         # tile_low_bits first when shrinking, tile_bits first when growing: keep every intermediate valid
         for key in sorted(options, key=lambda k: k != "tile_low_bits"):
             self.set_option(names[key], options[key])

@@ -85,18 +85,22 @@ def main():
             mono[r, c] = ph[r]
         cxm = np.eye(4)[[0, 1, 3, 2]].astype(complex)
         pair = cxm @ np.kron(np.diag([1, np.exp(0.3j)]), H)
-        for tb, tl in ((11, 6), (12, 6), (12, 7), (11, 5), (10, 5)):
+        for tb, tl in ((12, 4), (11, 4)):
             for label, M in (("dense", q4), ("pair", pair), ("mono", mono), ("cx", cxm)):
-                for nops in (1, 4, 8, 16):
+                for nops in (1, 2, 3, 4, 6, 8, 12, 16):
                     with Simulator(n, fuse=3, profile=True, tile_bits=tb, tile_low_bits=tl, tile_max_ops=64, grid_cap=a.grid_cap) as sim:
                         for q in range(n):
                             sim.apply_1q(H, q)
                         sim.sync()
 
                         def body():
+                            # spread the pairs over mid/high qubits (like a real pass) instead of the top five only
+                            qs = [n - 2, n - 5, n - 8, n - 11, n - 14, n - 17, n - 20, n - 23]
                             for j in range(nops):
-                                hi, lo = pairs[j % len(pairs)]
-                                sim.apply_2q(M, hi, lo)
+                                a_, b_ = qs[j % 8], qs[(j + 1 + (j // 8)) % 8]
+                                if a_ == b_:
+                                    b_ = qs[(j + 3) % 8]
+                                sim.apply_2q(M, max(a_, b_), min(a_, b_))
                             sim.flush()
                         ms, gbs, k = timed(sim, body, 5)
                         st = sim.stats()

@@ -363,3 +363,57 @@ def test_single_rank_process_group_bench_path(oracle, tmp_path):
         sim.close()
     finally:
         dist.destroy_process_group()
+
+
+def _perm_phase(rng, dim):
+    m = np.zeros((dim, dim), dtype=np.complex128)
+    for r, c in enumerate(rng.permutation(dim)):
+        m[r, c] = np.exp(1j * rng.uniform(-np.pi, np.pi))
+    return m
+
+
+@pytest.mark.parametrize("qubits", [(13, 9, 4), (12, 5, 0), (2, 1, 0), (13, 12, 11), (7, 3, 2), (10, 6, 1)])
+def test_sparse_block_forms_in_tile_passes(qubits):
+    """Every TOP_SP form (2 and 3 qubits; 1, 2 and 4 entries per row; identity rows) on low, mixed and high
+    tile-local bits: two-qubit gates with exact-zero structure on overlapping pairs are merged by the scheduler
+    into sparse 3-qubit blocks, replayed here with numpy."""
+    from helpers import np_apply_kq
+    n = 14
+    a, b, c = qubits
+    rng = np.random.default_rng(sum(qubits))
+    H = gate_matrix("h")
+    cx_hi = np.eye(4)[[0, 1, 3, 2]].astype(np.complex128)             # control = high qubit: two identity rows
+    pair = cx_hi @ np.kron(np.diag([1, np.exp(0.3j)]), H)             # two 2x2 blocks
+    gates = [(_perm_phase(rng, 4), (a, b)), (_perm_phase(rng, 4), (b, c)),   # monomial x monomial -> 3q, 1 entry/row
+             (pair, (a, b)), (_perm_phase(rng, 4), (b, c)),                  # pair x monomial     -> 3q, 2 entries/row
+             (pair, (a, b)), (pair, (b, c)),                                 # pair x pair         -> 3q, 4 entries/row
+             (cx_hi, (a, c)), (cx_hi, (b, c)),                               # bare CXs: identity rows
+             (random_unitary(4, rng), (a, c))]                               # dense 4x4
+    s0 = _rand_state(n, 77)
+    want = s0.copy()
+    with Simulator(n, fuse=3, tile_bits=10, tile_low_bits=3) as sim:
+        sim.write(s0)
+        for U, (hi, lo) in gates:
+            sim.apply_2q(U, hi, lo)
+            want = np_apply_kq(want, n, U, (hi, lo))
+        got = sim.read()
+        st = sim.stats()
+    assert np.max(np.abs(got - want)) < TOL
+    assert st["launches"] <= 3 and st["kernels"]["tile"]["launches"] >= 1  # the nine gates ran as one or two tile passes
+
+
+def test_largest_single_gpu_register():
+    """n = 33 (128 GiB): 64-bit indexing end to end; H on the top and bottom qubits, a CX across, norm and samples."""
+    n = 33
+    H = gate_matrix("h")
+    with Simulator(n, fuse=3) as sim:
+        sim.apply_1q(H, n - 1)
+        sim.apply_1q(H, 0)
+        sim.apply_cx(n - 1, 17)
+        sim.apply_1q(gate_matrix("t"), 17)
+        assert abs(sim.norm2() - 1.0) < 1e-12
+        lo = sim.read(0, 2)
+        hi = sim.read((1 << (n - 1)) | (1 << 17), 2)
+        assert np.allclose(lo, 0.5, atol=1e-15)
+        assert np.allclose(hi, 0.5 * np.exp(0.25j * np.pi), atol=1e-15)
+        assert abs(sim.read((1 << (n - 1)), 1)[0]) < 1e-15

@@ -154,7 +154,7 @@ extern "C" int qsim_set_option(qsim_state *s, int option, long value) {
         s->tile_bits = (int)value;
         break;
     case QSIM_OPT_TILE_LOW_BITS:
-        if (value < 2 || value > 11) return fail(QSIM_ERR_ARG, "tile_low_bits %ld not in 2..11", value);
+        if (value < 2 || value > 6) return fail(QSIM_ERR_ARG, "tile_low_bits %ld not in 2..6", value);
         s->tile_low_bits = (int)value;
         break;
     case QSIM_OPT_MAX_PENDING:

@@ -363,24 +363,37 @@ __global__ __launch_bounds__(THREADS) void k_tile(amp_t *__restrict__ v, TileDev
     const uint64_t first_tile = (uint64_t)blockIdx.x * (uint64_t)tiles_per_wg;
     if (first_tile >= ntiles) return;
     const int cnt = (int)((ntiles - first_tile) < (uint64_t)tiles_per_wg ? (ntiles - first_tile) : (uint64_t)tiles_per_wg);
+
+    // Element k of a lane is tile slot e = tid + k*THREADS.  With THREADS >= 2^L the run index e >> L splits without
+    // carry into (tid >> L) + k*(THREADS >> L), and the bit deposit is linear over disjoint bits, so the global byte
+    // offset of the element is  lane_off (per lane, once per workgroup)  +  k_off[k] (wave-uniform)  +  tile base.
+    // Tiles of a workgroup are consecutive: the next base is a masked increment, not another bit deposit.
+    // (the engine guarantees 2^L <= 64 <= THREADS)
+    const uint64_t lane_off = (hoff[(tid >> L) & ((1u << H) - 1u)] | (uint64_t)(tid & lowmask)) << 4;
+    uint64_t k_off[APT];
+#pragma unroll
+    for (int k = 0; k < APT; k++) k_off[k] = deposit((uint64_t)(k * THREADS) >> L, g.high_mask) << 4;
+    auto elem_ptr = [&](uint64_t tile_base, int k) -> amp_t * {
+        return reinterpret_cast<amp_t *>(reinterpret_cast<unsigned char *>(v) + ((tile_base << 4) + k_off[k]) + lane_off);
+    };
+    auto next_base = [&](uint64_t b) { return ((b | ~outer_mask) + 1ULL) & outer_mask; }; // +1 scattered over the outer bits
+
     amp_t pf[APT];
-    auto fetch = [&](uint64_t t) {
-        const uint64_t tb = deposit(t, outer_mask); // wave-uniform
+    auto fetch = [&](uint64_t tb) {
 #pragma unroll
         for (int k = 0; k < APT; k++) {
             const uint32_t e = tid + k * THREADS;
-            pf[k] = (FULL || e < E) ? v[tb | hoff[e >> L] | (uint64_t)(e & lowmask)] : amp_t{0.0, 0.0};
+            pf[k] = (FULL || e < E) ? *elem_ptr(tb, k) : amp_t{0.0, 0.0};
         }
     };
-    auto process = [&](uint64_t tile, bool prefetch_next) {
-        const uint64_t base = deposit(tile, outer_mask); // wave-uniform
+    auto process = [&](uint64_t base, bool prefetch_next) {
 #pragma unroll
         for (int k = 0; k < APT; k++) {
             const uint32_t e = tid + k * THREADS;
             if (FULL || e < E) lds[e] = pf[k];
         }
         __syncthreads();
-        if (prefetch_next) fetch(tile + 1);
+        if (prefetch_next) fetch(next_base(base));
 
         for (int oi = 0; oi < n_ops; oi++) {
             const int kind = ops[oi].kind;
@@ -471,14 +484,18 @@ __global__ __launch_bounds__(THREADS) void k_tile(amp_t *__restrict__ v, TileDev
 #pragma unroll
         for (int k = 0; k < APT; k++) {
             const uint32_t e = tid + k * THREADS;
-            if (FULL || e < E) v[base | hoff[e >> L] | (uint64_t)(e & lowmask)] = lds[e];
+            if (FULL || e < E) *elem_ptr(base, k) = lds[e];
         }
         __syncthreads();
     };
 
-    fetch(first_tile);
-    process(first_tile, cnt > 1);                                               // peeled first iteration
-    for (int j = 1; j < cnt; j++) process(first_tile + j, j + 1 < cnt);         // steady state; the last one fetches nothing
+    uint64_t base = deposit(first_tile, outer_mask); // wave-uniform
+    fetch(base);
+    process(base, cnt > 1);                                                   // peeled first iteration
+    for (int j = 1; j < cnt; j++) {                                           // steady state; the last one fetches nothing
+        base = next_base(base);
+        process(base, j + 1 < cnt);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -53,7 +53,7 @@ enum {
     QSIM_OPT_FUSE = 1,
     QSIM_OPT_PROFILE = 2,      /* 1: bracket every launch with HIP events on the engine's stream */
     QSIM_OPT_TILE_BITS = 3,    /* log2 amplitudes per LDS tile for level 3 (8..13, default 12 = 64 KiB) */
-    QSIM_OPT_TILE_LOW_BITS = 4,/* contiguous low index bits always inside a tile (2..11, default 3 -> 128-B runs, 9 free high-qubit slots) */
+    QSIM_OPT_TILE_LOW_BITS = 4,/* contiguous low index bits always inside a tile (2..6, default 3 -> 128-B runs, 9 free high-qubit slots) */
     QSIM_OPT_MAX_PENDING = 5,  /* queued gates that force a flush (default 1<<16) */
     QSIM_OPT_TILE_MAX_OPS = 6, /* upper bound on fused blocks per tile pass (default 32) */
     QSIM_OPT_GRID_CAP = 7,     /* 0: one workgroup per work tile; >0: at most that many workgroups (grid-stride loop) */

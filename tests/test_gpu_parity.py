@@ -118,8 +118,10 @@ def test_dense_2q_every_pair():
     (14, 400, 21, "all", {}),
     (16, 600, 22, "clifford_t", {}),
     (17, 500, 23, "all", {"tile_bits": 10, "tile_low_bits": 6}),
-    (18, 500, 24, "all", {"tile_bits": 13, "tile_low_bits": 7}),
-    (20, 300, 25, "all", {"tile_bits": 11, "tile_low_bits": 8, "tile_max_ops": 3}),
+    (18, 500, 24, "all", {"tile_bits": 13, "tile_low_bits": 6}),
+    (20, 300, 25, "all", {"tile_bits": 11, "tile_low_bits": 5, "tile_max_ops": 3}),
+    (19, 400, 27, "all", {"tile_bits": 9, "tile_low_bits": 2}),
+    (15, 400, 28, "clifford_t", {"tile_bits": 8, "tile_low_bits": 6}),
     (20, 300, 26, "all", {"grid_cap": 64}),
 ])
 def test_random_circuits_cache_blocked(oracle, tmp_path, n, depth, seed, vocab, opts):

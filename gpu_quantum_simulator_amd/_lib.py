@@ -53,6 +53,9 @@ SIGNATURES = {
     "qsim_norm2": (c_int, [c_void_p, _DP]),
     "qsim_device_ptr": (c_void_p, [c_void_p]),
     "qsim_stream": (c_void_p, [c_void_p]),
+    "qsim_sample": (c_int, [c_void_p, _DP, c_long, POINTER(c_uint64)]),
+    "qsim_draw_randn": (c_double, []),
+    "qsim_putb": (None, [ctypes.c_longlong, c_int, c_char_p]),
     "qsim_pack_bits": (c_int, [c_void_p, POINTER(c_int), c_int, c_void_p]),
     "qsim_scale": (c_int, [c_void_p, c_double, c_double]),
     "qsim_get_stats": (c_int, [c_void_p, POINTER(QsimStats)]),

@@ -510,6 +510,71 @@ extern "C" int qsim_norm2(qsim_state *s, double *out) {
     return QSIM_OK;
 }
 
+// ---- measurement post-path ----------------------------------------------------------------------------------
+extern "C" double qsim_draw_randn(void) { // measurement, quantum_simulator.c:271-276
+    double randn = 0.0, coeff = 1.0 / RAND_MAX;
+    for (int i = 0; i < 10; i++) {
+        randn += rand() * coeff;
+        coeff *= 1.0 / RAND_MAX;
+    }
+    return randn;
+}
+
+extern "C" void qsim_putb(long long n, int len, char *buf) { // putb, quantum_simulator.c:285-293
+    if (!buf || len < 0) return;
+    for (int k = 0; k < len; k++) buf[k] = ((n >> (len - 1 - k)) & 1) ? '1' : '0';
+    buf[len] = 0;
+}
+
+extern "C" int qsim_sample(qsim_state *s, const double *randoms, long shots, uint64_t *out) {
+    if (!s || (shots > 0 && (!randoms || !out))) return fail(QSIM_ERR_ARG, "NULL argument");
+    int rc = qsim_flush(s);
+    if (rc) return rc;
+    constexpr int kBlockBits = 12;
+    const uint64_t N = 1ULL << s->n;
+    const int bb = s->n < kBlockBits ? s->n : kBlockBits;
+    const uint64_t nblocks = N >> bb, bsize = 1ULL << bb;
+    double *d_part = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_part, nblocks * sizeof(double)));
+    LaunchCfg cfg{s->stream, s->grid_cap};
+    hipError_t e = launch_block_prob(cfg, s->amps, s->n, bb, d_part);
+    std::vector<double> prefix(nblocks);
+    if (e == hipSuccess) e = hipMemcpyAsync(prefix.data(), d_part, nblocks * sizeof(double), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    (void)hipFree(d_part);
+    if (e != hipSuccess) return fail(QSIM_ERR_DEVICE, "qsim_sample: %s", hipGetErrorString(e));
+    double acc = 0.0;
+    for (uint64_t b = 0; b < nblocks; b++) { acc += prefix[b]; prefix[b] = acc; } // cumulative at the END of block b
+
+    std::vector<double> blk(2 * bsize);
+    uint64_t cached = ~0ULL;
+    for (long k = 0; k < shots; k++) {
+        const double r = randoms[k];
+        // first block whose end value is non-zero and >= r (quantum_simulator.c:279: skip while == 0 or < r)
+        uint64_t lo = 0, hi = nblocks;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (prefix[mid] == 0.0 || prefix[mid] < r) lo = mid + 1;
+            else hi = mid;
+        }
+        uint64_t idx = N - 1;
+        bool found = false;
+        for (uint64_t b = lo; b < nblocks && !found; b++) { // normally one block; rounding can push it to the next
+            if (b != cached) {
+                HIP_TRY(hipMemcpy(blk.data(), s->amps + b * bsize, bsize * 16, hipMemcpyDeviceToHost));
+                cached = b;
+            }
+            double c = b ? prefix[b - 1] : 0.0;
+            for (uint64_t i = 0; i < bsize; i++) {
+                c += blk[2 * i] * blk[2 * i] + blk[2 * i + 1] * blk[2 * i + 1];
+                if (!(c == 0.0 || c < r)) { idx = b * bsize + i; found = true; break; }
+            }
+        }
+        out[k] = idx;
+    }
+    return QSIM_OK;
+}
+
 extern "C" int qsim_pack_bits(qsim_state *s, const int *bits, int nbits, void *dst) {
     if (!s || !bits || !dst) return fail(QSIM_ERR_ARG, "NULL argument");
     if (nbits < 1 || nbits > 8 || nbits > s->n) return fail(QSIM_ERR_ARG, "pack: %d bits unsupported", nbits);

@@ -517,6 +517,33 @@ __global__ __launch_bounds__(TPB) void k_norm2(const amp_t *__restrict__ v, uint
     }
 }
 
+// Probability mass per block of 2^block_bits amplitudes (measurement post-path).  One workgroup per block; the
+// reduction order is fixed (lane-strided partial sums, xor-butterfly inside the wave, waves added in order), so the
+// result does not depend on scheduling.
+__global__ __launch_bounds__(TPB) void k_block_prob(const amp_t *__restrict__ v, uint64_t N, int block_bits,
+                                                    double *__restrict__ out, uint64_t nblocks) {
+    __shared__ double part[TPB / 64];
+    for (uint64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const uint64_t lo = b << block_bits;
+        uint64_t hi = lo + (1ULL << block_bits);
+        if (hi > N) hi = N;
+        double acc = 0.0;
+        for (uint64_t i = lo + threadIdx.x; i < hi; i += TPB) {
+            const amp_t a = v[i];
+            acc += fma(a.x, a.x, a.y * a.y);
+        }
+        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < TPB / 64; w++) t += part[w];
+            out[b] = t;
+        }
+        __syncthreads();
+    }
+}
+
 // Shard re-layout ahead of a global<->local qubit exchange: gathers so that the p selected index bits
 // become the top p bits (the destination block id) while the other bits keep their order.  Writes are
 // fully coalesced; reads come in runs of 2^bits[0] amplitudes.
@@ -701,6 +728,15 @@ hipError_t launch_norm2(const LaunchCfg &cfg, const double2 *v, int n, double *d
     if (blocks > 4096) blocks = 4096;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(k_norm2, dim3((unsigned)blocks), dim3(TPB), 0, cfg.stream, (const amp_t *)v, N, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_block_prob(const LaunchCfg &cfg, const double2 *v, int n, int block_bits, double *d_out) {
+    const uint64_t N = 1ULL << n;
+    const uint64_t nblocks = (N + (1ULL << block_bits) - 1) >> block_bits;
+    uint64_t grid = nblocks > 65536 ? 65536 : nblocks;
+    hipLaunchKernelGGL(k_block_prob, dim3((unsigned)grid), dim3(TPB), 0, cfg.stream, (const amp_t *)v, N, block_bits, d_out,
+                       nblocks);
     return hipGetLastError();
 }
 

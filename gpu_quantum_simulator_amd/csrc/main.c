@@ -9,12 +9,15 @@
  *   QSIM_DUMP=<path>       raw little-endian doubles (re, im) of all 2^n amplitudes
  *   QSIM_DUMP_TEXT=<path>  "<index> <re> <im>" with %.17g, one amplitude per line
  *   QSIM_STATS=1           one JSON line on stderr: gates, launches, algorithmic bytes, GB/s
+ *   QSIM_MEASURE=1         after the time line, the <number_of_measurement> lines the reference has commented out
+ *                          (quantum_simulator.c:67-73): "MEASUREMENT: <bits> (<index>)", drawn like :270-283
  *   QSIM_DEVICE, QSIM_FUSE, QSIM_TILE_BITS, QSIM_TILE_LOW_BITS, QSIM_TILE_MAX_OPS, QSIM_GRID_CAP, QSIM_PROFILE
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/time.h>
+#include <time.h>
 
 #include "../../include/qsim.h"
 
@@ -80,6 +83,21 @@ int main(int argc, char *argv[]) {
     printf("%lf\n", t_exe); /* :248 */
     fflush(stdout);
 
+    if ((v = getenv("QSIM_MEASURE")) && *v && atoi(v) && argc > 2) {
+        const long shots = atol(argv[2]); /* num_m, quantum_simulator.c:50 */
+        const int nq = qsim_num_qubits(s);
+        srand((unsigned)time(NULL)); /* RAND PRE-HEAT, :45-47 */
+        for (int i = 0; i < 10; i++) rand();
+        char *bits = (char *)malloc((size_t)nq + 1);
+        for (long m = 0; m < shots && bits; m++) {
+            const double r = qsim_draw_randn();
+            uint64_t idx = 0;
+            if (qsim_sample(s, &r, 1, &idx) != QSIM_OK) { fprintf(stderr, "qsim: %s\n", qsim_last_error()); break; }
+            qsim_putb((long long)idx, nq, bits);
+            printf("MEASUREMENT: %s (%llu)\n", bits, (unsigned long long)idx);
+        }
+        free(bits);
+    }
     if ((v = getenv("QSIM_DUMP")) && *v && qsim_dump_raw(s, v) != QSIM_OK) fprintf(stderr, "qsim: dump failed: %s\n", qsim_last_error());
     if ((v = getenv("QSIM_DUMP_TEXT")) && *v && dump_text(s, v) != QSIM_OK) fprintf(stderr, "qsim: dump failed: %s\n", qsim_last_error());
     if ((v = getenv("QSIM_STATS")) && *v && atoi(v)) {

@@ -66,6 +66,8 @@ hipError_t launch_cx(const LaunchCfg &cfg, double2 *v, int n, int control, int t
 hipError_t launch_gate2(const LaunchCfg &cfg, double2 *v, int n, int q_hi, int q_lo, const M4 &U);
 hipError_t launch_tile(const LaunchCfg &cfg, double2 *v, const TileGeom &g, const TileOp *d_ops, int n_ops, int threads);
 hipError_t launch_norm2(const LaunchCfg &cfg, const double2 *v, int n, double *d_out /* zeroed */);
+// d_out[b] = sum of |a|^2 over amplitudes [b << block_bits, (b+1) << block_bits), fixed summation order
+hipError_t launch_block_prob(const LaunchCfg &cfg, const double2 *v, int n, int block_bits, double *d_out);
 // out[dst] = in[src]: dst = (block << (n-p)) | rest, where block = the p bits of src at positions
 // `bits` (ascending) and rest = the remaining n-p bits of src in order.
 hipError_t launch_pack(const LaunchCfg &cfg, const double2 *in, double2 *out, int n, const int *bits, int p);

@@ -222,6 +222,14 @@ class Simulator:
         a = np.ascontiguousarray(amps, dtype=np.complex128)
         check(_lib.load().qsim_write(self._h, first, a.size, _dp(a.view(np.float64))))
 
+    def sample(self, randoms) -> np.ndarray:
+        """Basis index measurement() (quantum_simulator.c:270-283) returns for each random number in [0, 1]."""
+        from ctypes import c_uint64
+        r = np.ascontiguousarray(randoms, dtype=np.float64)
+        out = np.zeros(r.size, dtype=np.uint64)
+        check(_lib.load().qsim_sample(self._h, _dp(r), r.size, out.ctypes.data_as(ctypes.POINTER(c_uint64))))
+        return out
+
     def norm2(self) -> float:
         v = c_double()
         check(_lib.load().qsim_norm2(self._h, byref(v)))

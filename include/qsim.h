@@ -116,6 +116,19 @@ int qsim_norm2(qsim_state *s, double *out); /* sum |a|^2 computed on the device 
 void *qsim_device_ptr(qsim_state *s);        /* amplitude array in HBM */
 void *qsim_stream(qsim_state *s);            /* the hipStream_t every launch goes to */
 
+/* ---- measurement post-path (dead code in the reference's main, quantum_simulator.c:67-73) ---- */
+/* compute_state_cumulative_distribution + the search of measurement (quantum_simulator.c:256-283) without ever
+ * materialising the 2^n-entry cumulative array: |a|^2 is summed per block of 4096 amplitudes on the device, the
+ * block sums are prefix-summed on the host, and only the block a draw falls into is scanned.  For every random
+ * number in randoms[0..shots) the result is the first basis index whose cumulative probability is non-zero and
+ * not below it, or 2^n - 1 (exactly the reference's loop; summation order differs from its strictly sequential
+ * one, so a draw within ~1e-15 of a boundary may land on the neighbouring index). */
+int qsim_sample(qsim_state *s, const double *randoms, long shots, uint64_t *out_indices);
+/* The random number measurement() draws (:271-276): ten rand() values, each scaled by a further 1/RAND_MAX. */
+double qsim_draw_randn(void);
+/* putb (:285-293): `len` binary digits of n, most significant first, NUL-terminated into buf (len + 1 bytes). */
+void qsim_putb(long long n, int len, char *buf);
+
 /* ---- sharded states (new: the reference is single-device) --------------------------------
  * A qsim_state may hold one contiguous shard of a larger register: the caller (one process per GPU)
  * keeps the top log2(P) index bits as the rank id and owns the logical->physical qubit map.

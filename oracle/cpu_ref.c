@@ -12,6 +12,9 @@
  *   oracle_gate_matrix   <- gate table                 :184-211 (PI = 2*asin(1), cexp for phases)
  *   oracle_run_qasm      <- compute_state_vector       :115-254 (two-statement header skip, char-level
  *                                                                 tokenizer, `qubit` allocation + |0..0>)
+ *   oracle_cumulative    <- compute_state_cumulative_distribution :256-268
+ *   oracle_measure / oracle_draw_randn <- measurement  :270-283
+ *   oracle_putb          <- putb                       :285-293
  *
  * Parity pinning: tests/test_oracle_golden.py checks this file bit-for-bit against tests/golden/*.npy,
  * which were produced by the real reference compiled from /root/reference (oracle/Makefile target
@@ -258,6 +261,48 @@ double *oracle_run_qasm(const char *path, int *num_q, double *seconds, long max_
 }
 
 void oracle_free(double *p) { free(p); }
+
+/* ---- measurement post-path (:256-293; the call site in main, :67-73, is commented out in the reference) ---- */
+
+/* compute_state_cumulative_distribution (:256-268): cumul[i] = sum_{k<=i} cabs(v[k])*cabs(v[k]), accumulated in
+ * index order.  (The reference allocates twice the bytes it needs, B10; harmless, not reproduced.) */
+double *oracle_cumulative(const double *state, int num_q) {
+    const uint64_t dim = 1ULL << num_q;
+    double *res = (double *)malloc(sizeof(double) * dim);
+    if (!res) return NULL;
+    double acc = 0.0;
+    for (uint64_t i = 0; i < dim; i++) {
+        const double a = cabs(state[2 * i] + I * state[2 * i + 1]);
+        acc += a * a;
+        res[i] = acc;
+    }
+    return res;
+}
+
+/* The search of measurement (:278-282) for a given random number: the first index whose cumulative value is
+ * non-zero and not below randn, or 2^n - 1.  (The reference draws randn itself from rand(), :271-276.) */
+long long oracle_measure(const double *cumul, int num_q, double randn) {
+    const long long last = (long long)((1ULL << num_q) - 1);
+    long long idx = 0;
+    while ((cumul[idx] == 0.0 || cumul[idx] < randn) && idx < last) idx++;
+    return idx;
+}
+
+/* measurement's random number (:271-276): ten rand() draws, each scaled by a further 1/RAND_MAX. */
+double oracle_draw_randn(void) {
+    double randn = 0.0, coeff = 1.0 / RAND_MAX;
+    for (int i = 0; i < 10; i++) {
+        randn += rand() * coeff;
+        coeff *= 1.0 / RAND_MAX;
+    }
+    return randn;
+}
+
+/* putb (:285-293): n as `len` binary digits, most significant first, into buf (len + 1 bytes). */
+void oracle_putb(long long n, int len, char *buf) {
+    for (int k = 0; k < len; k++) buf[k] = ((n >> (len - 1 - k)) & 1) ? '1' : '0';
+    buf[len] = 0;
+}
 
 /* Fresh |0...0> of n qubits (:168-177), for kernel-level tests that do not go through a file. */
 double *oracle_alloc_zero_state(int num_q) {

@@ -38,6 +38,12 @@ def lib() -> ctypes.CDLL:
                                       ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_int)]
         L.oracle_run_qasm.restype = ctypes.c_void_p
         L.oracle_free.argtypes = [ctypes.c_void_p]
+        L.oracle_cumulative.argtypes = [dp, ctypes.c_int]
+        L.oracle_cumulative.restype = ctypes.c_void_p
+        L.oracle_measure.argtypes = [dp, ctypes.c_int, ctypes.c_double]
+        L.oracle_measure.restype = ctypes.c_longlong
+        L.oracle_draw_randn.restype = ctypes.c_double
+        L.oracle_putb.argtypes = [ctypes.c_longlong, ctypes.c_int, ctypes.c_char_p]
         _LIB = L
     return _LIB
 
@@ -79,6 +85,24 @@ def run_qasm(path: str, max_gates: int = -1):
     a = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_double)), shape=(2 << n.value,)).copy()
     lib().oracle_free(p)
     return n.value, a.view(np.complex128), secs.value, done.value
+
+
+def cumulative(state: np.ndarray, n: int) -> np.ndarray:
+    """compute_state_cumulative_distribution (quantum_simulator.c:256-268)."""
+    p = lib().oracle_cumulative(_dp(np.ascontiguousarray(state).view(np.float64)), n)
+    out = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_double)), shape=(1 << n,)).copy()
+    lib().oracle_free(p)
+    return out
+
+
+def measure(cumul: np.ndarray, n: int, randn: float) -> int:
+    return int(lib().oracle_measure(_dp(cumul), n, randn))
+
+
+def putb(value: int, length: int) -> str:
+    buf = ctypes.create_string_buffer(length + 1)
+    lib().oracle_putb(value, length, buf)
+    return buf.value.decode()
 
 
 def zero_state(n: int) -> np.ndarray:

@@ -419,3 +419,34 @@ def test_largest_single_gpu_register():
         assert np.allclose(lo, 0.5, atol=1e-15)
         assert np.allclose(hi, 0.5 * np.exp(0.25j * np.pi), atol=1e-15)
         assert abs(sim.read((1 << (n - 1)), 1)[0]) < 1e-15
+
+
+def test_measurement_post_path(oracle, golden_dir, tmp_path):
+    """qsim_sample against the oracle's cumulative distribution + search (quantum_simulator.c:256-283)."""
+    n = 14
+    path = circuits.random_circuit_file(str(tmp_path / "c.qasm"), n, 300, 91, "all")
+    _, want_state, _, _ = oracle.run_qasm(path)
+    cumul = oracle.cumulative(want_state, n)
+    rng = np.random.default_rng(3)
+    draws = np.concatenate([rng.uniform(0, 1, 300), [0.0, 1e-300, 0.5, 1.0, 1.5]])
+    c = Circuit.from_file(path)
+    with Simulator(n) as sim:
+        sim.run(c)
+        got = sim.sample(draws)
+    mism = 0
+    for r, g in zip(draws, got):
+        w = oracle.measure(cumul, n, float(r))
+        if int(g) != w:  # only allowed when the draw sits on a boundary to within rounding of the summation order
+            assert abs(int(g) - w) == 1 and min(abs(cumul[w] - r), abs(cumul[int(g)] - r)) < 1e-13
+            mism += 1
+    assert mism <= 2
+    # a state with leading zero amplitudes: cumul == 0 entries are skipped
+    with Simulator(6) as sim:
+        sim.apply_1q(gate_matrix("x"), 5)
+        assert list(sim.sample([0.0, 0.3, 1.0])) == [32, 32, 32]
+    # CLI: the lines the reference has commented out, behind QSIM_MEASURE
+    env = dict(os.environ, QSIM_MEASURE="1")
+    p = subprocess.run([_lib.CLI_PATH, os.path.join(golden_dir, "entanglement.qasm"), "5"], capture_output=True, text=True, env=env)
+    lines = p.stdout.splitlines()
+    assert p.returncode == 0 and len(lines) == 6 and float(lines[0]) >= 0
+    assert all(l in ("MEASUREMENT: 00 (0)", "MEASUREMENT: 11 (3)") for l in lines[1:])

@@ -125,3 +125,34 @@ def test_oracle_kernels_equal_live_reference(oracle):
         oracle.apply_cx(a, n, q, (q + 3) % n)
         R.execute_cnot(b.view(np.float64).ctypes.data_as(dp), n, q, (q + 3) % n)
     assert a.tobytes() == b.tobytes()
+
+
+def test_measurement_post_path_equals_live_reference(oracle, golden_dir):
+    """quantum_simulator.c:256-293 (dead code in the reference's main, still compiled into oracle/_ref)."""
+    if not oracle.have_reference():
+        pytest.skip("oracle/_ref not built")
+    import ctypes
+    R = oracle.reference_lib()
+    dp = ctypes.POINTER(ctypes.c_double)
+    R.compute_state_cumulative_distribution.argtypes = [dp, ctypes.c_int]
+    R.compute_state_cumulative_distribution.restype = ctypes.c_void_p
+    R.measurement.argtypes = [dp, ctypes.c_int]
+    R.measurement.restype = ctypes.c_longlong
+    libc = ctypes.CDLL(None)
+    n, amps, _, _ = oracle.run_qasm(os.path.join(golden_dir, "rand_n10_all.qasm"))
+    p = R.compute_state_cumulative_distribution(amps.view(np.float64).ctypes.data_as(dp), n)
+    ref_cumul = np.ctypeslib.as_array(ctypes.cast(p, dp), shape=(1 << n,)).copy()
+    got = oracle.cumulative(amps, n)
+    assert got.tobytes() == ref_cumul.tobytes()
+    for seed in range(1, 40):
+        libc.srand(seed)
+        want = R.measurement(ref_cumul.ctypes.data_as(dp), n)
+        libc.srand(seed)
+        randn = oracle.lib().oracle_draw_randn()
+        assert oracle.measure(got, n, randn) == want
+    libc.free(ctypes.c_void_p(p))
+    assert oracle.putb(5, 6) == "000101" and oracle.putb(63, 6) == "111111"
+    # all-zero prefix is skipped (cumul == 0), a draw above the total lands on the last index
+    c = np.array([0.0, 0.0, 0.25, 0.25, 1.0, 1.0, 1.0, 1.0])
+    assert oracle.measure(c, 3, 0.0) == 2 and oracle.measure(c, 3, 0.25) == 2 and oracle.measure(c, 3, 0.26) == 4
+    assert oracle.measure(c, 3, 1.5) == 7

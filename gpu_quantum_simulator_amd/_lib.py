@@ -58,6 +58,19 @@ SIGNATURES = {
     "qsim_putb": (None, [ctypes.c_longlong, c_int, c_char_p]),
     "qsim_pack_bits": (c_int, [c_void_p, POINTER(c_int), c_int, c_void_p]),
     "qsim_scale": (c_int, [c_void_p, c_double, c_double]),
+    "qsim_cluster_create": (c_int, [POINTER(c_void_p), c_int, c_int, POINTER(c_int)]),
+    "qsim_cluster_destroy": (None, [c_void_p]),
+    "qsim_cluster_num_shards": (c_int, [c_void_p]),
+    "qsim_cluster_shard": (c_void_p, [c_void_p, c_int]),
+    "qsim_cluster_set_option": (c_int, [c_void_p, c_int, c_long]),
+    "qsim_cluster_reset": (c_int, [c_void_p]),
+    "qsim_cluster_run_circuit": (c_int, [c_void_p, c_void_p]),
+    "qsim_cluster_sync": (c_int, [c_void_p]),
+    "qsim_cluster_read": (c_int, [c_void_p, c_uint64, c_uint64, _DP]),
+    "qsim_cluster_norm2": (c_int, [c_void_p, _DP]),
+    "qsim_cluster_exchange_stats": (c_int, [c_void_p, POINTER(c_uint64), _DP]),
+    "qsim_cluster_error": (c_char_p, []),
+    "qsim_plan_shards": (c_long, [c_void_p, c_int, POINTER(c_int), c_long, POINTER(c_int), POINTER(c_int)]),
     "qsim_get_stats": (c_int, [c_void_p, POINTER(QsimStats)]),
     "qsim_reset_stats": (c_int, [c_void_p]),
     "qsim_launch_log": (c_long, [c_void_p, c_long, POINTER(c_int), POINTER(c_int), POINTER(c_uint64), POINTER(c_double)]),

@@ -11,6 +11,8 @@
  *   QSIM_STATS=1           one JSON line on stderr: gates, launches, algorithmic bytes, GB/s
  *   QSIM_MEASURE=1         after the time line, the <number_of_measurement> lines the reference has commented out
  *                          (quantum_simulator.c:67-73): "MEASUREMENT: <bits> (<index>)", drawn like :270-283
+ *   QSIM_SHARDS=P          split the register over P = 2^p shards driven by this process: devices round-robin over the
+ *                          visible GPUs (all on one GPU = virtual shards); QSIM_DUMP then writes LOGICAL order
  *   QSIM_DEVICE, QSIM_FUSE, QSIM_TILE_BITS, QSIM_TILE_LOW_BITS, QSIM_TILE_MAX_OPS, QSIM_GRID_CAP, QSIM_PROFILE
  */
 #include <stdio.h>
@@ -47,6 +49,50 @@ static int dump_text(qsim_state *s, const char *path) {
     return rc;
 }
 
+/* The multi-GPU path of the C host: same stdout contract, state sharded over QSIM_SHARDS shards. */
+static int run_sharded(qsim_circuit *c, int shards, double t_start) {
+    qsim_cluster *cl = NULL;
+    const char *v;
+    int rc = qsim_cluster_create(&cl, qsim_circuit_num_qubits(c), shards, NULL);
+    if (rc == QSIM_OK && (v = getenv("QSIM_FUSE")) && *v) rc = qsim_cluster_set_option(cl, QSIM_OPT_FUSE, atol(v));
+    if (rc == QSIM_OK) rc = qsim_cluster_reset(cl);
+    if (rc == QSIM_OK) rc = qsim_cluster_run_circuit(cl, c);
+    if (rc == QSIM_OK) rc = qsim_cluster_sync(cl);
+    if (rc != QSIM_OK) {
+        if (rc == QSIM_ERR_ALLOC) printf("Malloc error\n");
+        else printf("ERROR: %s\n", qsim_cluster_error());
+        printf("ERROR while parsing quantum circuit\n");
+        exit(1);
+    }
+    const double t_exe = wall_seconds() - t_start;
+    printf("%lf\n", t_exe);
+    fflush(stdout);
+    if ((v = getenv("QSIM_DUMP")) && *v) {
+        const int n = qsim_circuit_num_qubits(c);
+        const uint64_t N = 1ULL << n, chunk = N < (1ULL << 20) ? N : (1ULL << 20);
+        double *buf = (double *)malloc((size_t)chunk * 16);
+        FILE *f = fopen(v, "wb");
+        for (uint64_t at = 0; buf && f && at < N; at += chunk)
+            if (qsim_cluster_read(cl, at, chunk, buf) != QSIM_OK || fwrite(buf, 16, (size_t)chunk, f) != (size_t)chunk) {
+                fprintf(stderr, "qsim: dump failed: %s\n", qsim_cluster_error());
+                break;
+            }
+        if (f) fclose(f);
+        free(buf);
+    }
+    if ((v = getenv("QSIM_STATS")) && *v && atoi(v)) {
+        uint64_t ex = 0;
+        double bytes = 0;
+        qsim_cluster_exchange_stats(cl, &ex, &bytes);
+        fprintf(stderr, "{\"qubits\": %d, \"shards\": %d, \"gates\": %ld, \"seconds\": %.6f, \"exchanges\": %llu, "
+                        "\"exchange_bytes_per_shard\": %.0f}\n",
+                qsim_circuit_num_qubits(c), shards, qsim_circuit_num_gates(c), t_exe, (unsigned long long)ex, bytes);
+    }
+    qsim_circuit_free(c);
+    qsim_cluster_destroy(cl);
+    return 0;
+}
+
 int main(int argc, char *argv[]) {
     if (argc < 2) { /* quantum_simulator.c:39-43 */
         printf("QUANTUM CIRCUIT SIMULATOR\n");
@@ -68,6 +114,8 @@ int main(int argc, char *argv[]) {
         printf("ERROR while parsing quantum circuit\n"); /* :55-58 */
         exit(1);
     }
+    const int shards = (v = getenv("QSIM_SHARDS")) && *v ? atoi(v) : 1;
+    if (shards > 1) return run_sharded(c, shards, t_start);
     const int device = (v = getenv("QSIM_DEVICE")) && *v ? atoi(v) : 0;
     rc = qsim_create(&s, qsim_circuit_num_qubits(c), device);
     if (rc == QSIM_OK) rc = qsim_apply_env_options(s);

@@ -265,6 +265,86 @@ class Simulator:
         check(_lib.load().qsim_reset_stats(self._h))
 
 
+class Cluster:
+    """qsim_cluster: P shards driven by this one process (the C host's multi-GPU path; repeat a device for virtual shards)."""
+
+    def __init__(self, num_q: int, num_shards: int, devices: Optional[Sequence[int]] = None, **options):
+        self._h = c_void_p()
+        lib = _lib.load()
+        arr = (c_int * num_shards)(*devices) if devices is not None else None
+        rc = lib.qsim_cluster_create(byref(self._h), num_q, num_shards, arr)
+        if rc:
+            raise _lib.QsimError(rc, (lib.qsim_cluster_error() or b"").decode())
+        self.num_qubits, self.num_shards = num_q, num_shards
+        names = {"fuse": _lib.OPT_FUSE, "tile_bits": _lib.OPT_TILE_BITS, "tile_low_bits": _lib.OPT_TILE_LOW_BITS,
+                 "tile_max_ops": _lib.OPT_TILE_MAX_OPS, "profile": _lib.OPT_PROFILE}
+        for key in sorted(options, key=lambda k: k != "tile_low_bits"):
+            self._check(lib.qsim_cluster_set_option(self._h, names[key], int(options[key])))
+
+    def _check(self, rc):
+        if rc:
+            raise _lib.QsimError(rc, (_lib.load().qsim_cluster_error() or b"").decode())
+
+    def run(self, circuit: Circuit) -> None:
+        lib = _lib.load()
+        self._check(lib.qsim_cluster_reset(self._h))
+        self._check(lib.qsim_cluster_run_circuit(self._h, circuit._h))
+        self._check(lib.qsim_cluster_sync(self._h))
+
+    def read(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        if count is None:
+            count = (1 << self.num_qubits) - first
+        out = np.empty(2 * count, dtype=np.float64)
+        self._check(_lib.load().qsim_cluster_read(self._h, first, count, _dp(out)))
+        return out.view(np.complex128)
+
+    def norm2(self) -> float:
+        v = c_double()
+        self._check(_lib.load().qsim_cluster_norm2(self._h, byref(v)))
+        return v.value
+
+    def exchange_stats(self):
+        from ctypes import c_uint64
+        n, b = c_uint64(), c_double()
+        _lib.load().qsim_cluster_exchange_stats(self._h, byref(n), byref(b))
+        return int(n.value), float(b.value)
+
+    def close(self) -> None:
+        if self._h:
+            _lib.load().qsim_cluster_destroy(self._h)
+            self._h = c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def plan_shards(circuit: Circuit, num_shards: int):
+    """The C++ planner's exchanges [(shard_bits, local_positions)], final logical->physical map and local-step count."""
+    lib = _lib.load()
+    cap = 4096
+    buf = (c_int * cap)()
+    pos = (c_int * circuit.num_qubits)()
+    locals_ = c_int()
+    w = lib.qsim_plan_shards(circuit._h, num_shards, buf, cap, pos, byref(locals_))
+    if w < 0 or w > cap:
+        raise RuntimeError("qsim_plan_shards failed")
+    out, i = [], 0
+    while i < w:
+        k = buf[i]
+        out.append((tuple(buf[i + 1:i + 1 + k]), tuple(buf[i + 1 + k:i + 1 + 2 * k])))
+        i += 1 + 2 * k
+    return out, list(pos), locals_.value
+
+
 def run_qasm(path: str, device: int = 0, **sim_options) -> np.ndarray:
     """QASM file in, amplitude vector out (the drop-in path of BASELINE.json's north_star)."""
     c = Circuit.from_file(path)

@@ -141,6 +141,31 @@ int qsim_pack_bits(qsim_state *s, const int *bits, int nbits, void *dst_device);
 /* Multiplies every amplitude of the shard by (re, im): a diagonal gate on a global qubit is a per-rank scalar. */
 int qsim_scale(qsim_state *s, double re, double im);
 
+/* ---- clusters: P = 2^p shards driven by ONE process (the C host's multi-GPU path) --------------------------
+ * Each shard is a qsim_state on devices[r] (NULL: round-robin over the visible devices; the same device may
+ * repeat, which gives "virtual shards" for validation on fewer GPUs).  qsim_cluster_run_circuit plans the
+ * circuit (logical->physical qubit map, communication-free handling of diagonal gates / controls on global
+ * qubits, Belady choice of the qubits that become global) and executes it: local steps through the ordinary
+ * engine, exchanges as qsim_pack_bits + device-to-device block copies.  The one-process-per-GPU driver
+ * (gpu_quantum_simulator_amd/distributed.py) runs the same plan with RCCL send/recv. */
+typedef struct qsim_cluster qsim_cluster;
+int qsim_cluster_create(qsim_cluster **out, int num_q, int num_shards, const int *devices);
+void qsim_cluster_destroy(qsim_cluster *c);
+int qsim_cluster_num_shards(const qsim_cluster *c);
+qsim_state *qsim_cluster_shard(qsim_cluster *c, int shard);
+int qsim_cluster_set_option(qsim_cluster *c, int option, long value);
+int qsim_cluster_reset(qsim_cluster *c); /* |0...0>, identity qubit map */
+int qsim_cluster_run_circuit(qsim_cluster *c, const qsim_circuit *circuit);
+int qsim_cluster_sync(qsim_cluster *c);
+int qsim_cluster_read(qsim_cluster *c, uint64_t logical_first, uint64_t count, double *out_re_im);
+int qsim_cluster_norm2(qsim_cluster *c, double *out);
+int qsim_cluster_exchange_stats(const qsim_cluster *c, uint64_t *exchanges, double *bytes_per_shard);
+const char *qsim_cluster_error(void);
+/* Host-only planner output: per exchange k, then k shard-id bits, then k local bit positions (ascending, paired).
+ * Returns the number of ints written (or needed), -1 on error. */
+long qsim_plan_shards(const qsim_circuit *circuit, int num_shards, int *steps_out, long cap, int *final_pos,
+                      int *n_local_steps);
+
 int qsim_get_stats(qsim_state *s, qsim_stats *out); /* waits for outstanding profile events */
 int qsim_reset_stats(qsim_state *s);
 /* Per-launch record (QSIM_OPT_PROFILE=1) since the last qsim_reset_stats: returns the number of records and,

@@ -126,3 +126,19 @@ def test_gloo_ranks_equal_oracle(oracle, tmp_path, world):
     for rank, err, norm, aerr, exchanges, xbytes in results:
         assert err < TOL and abs(norm - 1.0) < 1e-12 and aerr < TOL
         assert exchanges >= 1 and xbytes > 0
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("n,depth,seed,vocab", [(8, 300, 11, "all"), (12, 600, 12, "all"), (16, 800, 13, "clifford_t"),
+                                                (30, 1000, 20240147, "all")])
+def test_cpp_planner_equals_python_planner(world, n, depth, seed, vocab):
+    """libqsim's planner (csrc/dist.cpp, used by the C host) and distributed.ShardPlan (used by the torch.distributed
+    driver) must produce the same exchanges and the same final qubit map."""
+    from gpu_quantum_simulator_amd import Circuit, plan_shards
+    gates = circuits.random_gates(n, depth, seed, vocab)
+    p = world.bit_length() - 1
+    py = ShardPlan(n, p, normalize_gates(gates, gate_matrix), rank=0)
+    exchanges, final_pos, n_local = plan_shards(Circuit.from_gates(n, gates), world)
+    assert exchanges == [(s[1], s[2]) for s in py.steps if s[0] == "exchange"]
+    assert final_pos == py.final_pos
+    assert n_local == sum(1 for s in py.steps if s[0] == "local")

@@ -450,3 +450,31 @@ def test_measurement_post_path(oracle, golden_dir, tmp_path):
     lines = p.stdout.splitlines()
     assert p.returncode == 0 and len(lines) == 6 and float(lines[0]) >= 0
     assert all(l in ("MEASUREMENT: 00 (0)", "MEASUREMENT: 11 (3)") for l in lines[1:])
+
+
+@pytest.mark.parametrize("shards", [2, 4, 8])
+def test_c_host_cluster_virtual_shards(oracle, tmp_path, shards):
+    """qsim_cluster (csrc/dist.cpp): the C host's one-process sharded path, all shards on device 0."""
+    from gpu_quantum_simulator_amd import Cluster
+    n = 17
+    path = circuits.random_circuit_file(str(tmp_path / "c.qasm"), n, 600, 80 + shards, "all")
+    _, want, _, _ = oracle.run_qasm(path)
+    c = Circuit.from_file(path)
+    with Cluster(n, shards, devices=[0] * shards) as cl:
+        for _ in range(2):  # a second run must start from a clean state and map
+            cl.run(c)
+        assert abs(cl.norm2() - 1.0) < 1e-10
+        got = cl.read()
+        assert np.max(np.abs(got - want)) < TOL
+        assert np.max(np.abs(cl.read(12345, 7) - want[12345:12352])) < TOL  # the one-by-one path
+        ex, nbytes = cl.exchange_stats()
+        assert ex >= 2 and nbytes > 0
+
+
+def test_cli_sharded(oracle, golden_dir, tmp_path):
+    dump = str(tmp_path / "amps.bin")
+    env = dict(os.environ, QSIM_SHARDS="4", QSIM_DUMP=dump, QSIM_STATS="1")
+    p = subprocess.run([_lib.CLI_PATH, os.path.join(golden_dir, "rand_n12_all.qasm"), "1"], capture_output=True, text=True, env=env)
+    assert p.returncode == 0 and len(p.stdout.splitlines()) == 1 and '"shards": 4' in p.stderr
+    want = np.load(os.path.join(golden_dir, "rand_n12_all.npy")).view(np.complex128).reshape(-1)
+    assert np.max(np.abs(np.fromfile(dump, dtype=np.complex128) - want)) < TOL

@@ -461,13 +461,11 @@ extern "C" int qsim_flush(qsim_state *s) {
         else sched.add_2q(g.m, g.q0, g.q1);
     }
     s->queue.clear();
-    std::vector<Pass> passes;
-    sched.finish(passes);
-    for (const Pass &p : passes) {
-        const int rc = launch_pass(s, p);
-        if (rc) return rc;
-    }
-    return QSIM_OK;
+    int rc = QSIM_OK;
+    sched.finish([&](Pass &&p) { // launched as soon as it is scheduled: the GPU works while later passes are planned
+        if (rc == QSIM_OK) rc = launch_pass(s, p);
+    });
+    return rc;
 }
 
 extern "C" int qsim_sync(qsim_state *s) {

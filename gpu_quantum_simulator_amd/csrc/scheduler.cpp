@@ -175,15 +175,19 @@ void Scheduler::fold_2q(const cd U[16], int q_hi, int q_lo, uint32_t gates) {
     open_[q_hi] = open_[q_lo] = (int)pool_.size() - 1;
 }
 
-void Scheduler::finish(std::vector<Pass> &out) {
+void Scheduler::finish(const PassSink &sink) {
     for (int q = 0; q < cfg_.n; q++) close(open_[q]);
     pool_.clear();
-    build_passes(out);
+    build_passes(sink);
     closed_.clear();
 }
 
+void Scheduler::finish(std::vector<Pass> &out) {
+    finish([&out](Pass &&p) { out.push_back(std::move(p)); });
+}
+
 // ---- pass construction --------------------------------------------------------------------------------
-void Scheduler::single_op_pass(const FusedOp &op, std::vector<Pass> &out) const {
+void Scheduler::single_op_pass(const FusedOp &op, const PassSink &sink) const {
     const double S = 16.0 * (double)(1ULL << cfg_.n); // bytes of state
     Pass p;
     p.ops.push_back(op);
@@ -198,24 +202,24 @@ void Scheduler::single_op_pass(const FusedOp &op, std::vector<Pass> &out) const 
             p.kclass = op.q_hi >= 6 ? QSIM_K_GATE1 : QSIM_K_GATE1_LO;
             p.bytes = 2 * S;
         }
-        out.push_back(std::move(p));
+        sink(std::move(p));
     } else if (op.kind == OP_CX) {
         p.kclass = QSIM_K_CX;
         p.bytes = S;
-        out.push_back(std::move(p));
+        sink(std::move(p));
     } else {
         if (op.is_identity()) return;
-        if (op.q_lo >= 6) {
+        if (op.kind == OP_G2 && op.q_lo >= 6) {
             p.kclass = QSIM_K_GATE2;
             p.bytes = 2 * S;
-            out.push_back(std::move(p));
+            sink(std::move(p));
         } else {
-            tile_pass(p.ops, out);
+            tile_pass(p.ops, sink);
         }
     }
 }
 
-void Scheduler::tile_pass(const std::vector<FusedOp> &ops, std::vector<Pass> &out) const {
+void Scheduler::tile_pass(const std::vector<FusedOp> &ops, const PassSink &sink) const {
     const int B = std::min(cfg_.tile_bits, cfg_.n);
     const int L = std::min(cfg_.tile_low_bits, B);
     Pass p;
@@ -238,12 +242,12 @@ void Scheduler::tile_pass(const std::vector<FusedOp> &ops, std::vector<Pass> &ou
     p.geom.n_high = 0;
     for (int b = L; b < cfg_.n; b++)
         if (high >> b & 1ULL) p.geom.high[p.geom.n_high++] = b;
-    out.push_back(std::move(p));
+    sink(std::move(p));
 }
 
-void Scheduler::build_passes(std::vector<Pass> &out) {
+void Scheduler::build_passes(const PassSink &sink) {
     if (cfg_.fuse <= 2) {
-        for (const FusedOp &op : closed_) single_op_pass(op, out);
+        for (const FusedOp &op : closed_) single_op_pass(op, sink);
         return;
     }
     const int B = std::min(cfg_.tile_bits, cfg_.n);
@@ -252,50 +256,84 @@ void Scheduler::build_passes(std::vector<Pass> &out) {
     const uint64_t lowmask = (1ULL << L) - 1ULL;
     const uint64_t all = cfg_.n >= 64 ? ~0ULL : ((1ULL << cfg_.n) - 1ULL);
     const size_t m = closed_.size();
-    std::vector<char> done(m, 0);
+    std::vector<uint64_t> qm(m);
+    for (size_t i = 0; i < m; i++) qm[i] = closed_[i].qmask();
+    std::vector<char> done(m, 0), trial;
     size_t first = 0;
     std::vector<FusedOp> group;
+    struct Cand { long idx; int need; };
+
+    // Runnable blocks under the qubits chosen so far, cheapest (fewest new high-qubit slots) first.  A block is
+    // runnable when no earlier pending block shares a qubit with it, directly or through a chain of pending blocks
+    // (those qubits are "blocked"), so emitting blocks in the order they are picked respects every dependency.
+    auto scan = [&](const std::vector<char> &dn, size_t from, size_t to, uint64_t hset, std::vector<Cand> *cands) -> Cand {
+        Cand best{-1, 1 << 30};
+        uint64_t blocked = 0;
+        const int used = __builtin_popcountll(hset);
+        for (size_t i = from; i < to; i++) {
+            if (dn[i]) continue;
+            if (!(qm[i] & blocked)) {
+                const int need = __builtin_popcountll(qm[i] & ~lowmask & ~hset);
+                if (used + need <= kmax) {
+                    if (cands) cands->push_back({(long)i, need});
+                    if (need < best.need) {
+                        best = {(long)i, need};
+                        if (need == 0) return best; // free: take it right away
+                    }
+                }
+            }
+            blocked |= qm[i];
+            if (blocked == all) break;
+        }
+        return best;
+    };
+    // how many blocks a pass reaches when it is finished greedily from (dn, hset)
+    auto rollout = [&](std::vector<char> &dn, size_t from, size_t to, uint64_t hset, int have) {
+        int cnt = 0;
+        while (have + cnt < cfg_.tile_max_ops) {
+            const Cand c = scan(dn, from, to, hset, nullptr);
+            if (c.idx < 0) break;
+            dn[(size_t)c.idx] = 1;
+            hset |= qm[(size_t)c.idx] & ~lowmask;
+            cnt++;
+        }
+        return cnt;
+    };
+
+    std::vector<Cand> cands;
     while (first < m) {
         if (done[first]) { first++; continue; }
         group.clear();
         uint64_t hset = 0;
         const size_t end = std::min(m, first + (size_t)cfg_.window);
-        // Grow the pass one block at a time, always taking the runnable block that needs the FEWEST new high-qubit
-        // slots (blocks that fit the qubits already chosen are free), earliest first among equals.  A block is
-        // runnable when no earlier pending block shares a qubit with it, directly or through a chain of pending
-        // blocks (those qubits are "blocked"), so emitting blocks in the order they are picked respects every
-        // dependency.
         while ((int)group.size() < cfg_.tile_max_ops) {
-            uint64_t blocked = 0;
-            long best = -1;
-            int best_need = 1 << 30;
-            for (size_t i = first; i < end; i++) {
-                if (done[i]) continue;
-                const uint64_t qmask = closed_[i].qmask();
-                if (!(qmask & blocked)) {
-                    const int need = __builtin_popcountll(qmask & ~lowmask & ~hset);
-                    if (__builtin_popcountll(hset) + need <= kmax && need < best_need) {
-                        best = (long)i;
-                        best_need = need;
-                        if (need == 0) break;
-                    }
+            cands.clear();
+            Cand pick = scan(done, first, end, hset, cfg_.rollout > 1 ? &cands : nullptr);
+            if (pick.idx < 0) break;
+            if (pick.need > 0 && cfg_.rollout > 1 && cands.size() > 1) {
+                // a new qubit has to be admitted: try the cheapest few candidates and keep the one after which a
+                // greedy completion of this pass absorbs the most blocks
+                std::stable_sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.need < b.need; });
+                int best_score = -1;
+                const size_t tries = std::min(cands.size(), (size_t)cfg_.rollout);
+                for (size_t t = 0; t < tries; t++) {
+                    trial = done;
+                    trial[(size_t)cands[t].idx] = 1;
+                    const int score = rollout(trial, first, end, hset | (qm[(size_t)cands[t].idx] & ~lowmask), (int)group.size() + 1);
+                    if (score > best_score) { best_score = score; pick = cands[t]; }
                 }
-                blocked |= qmask; // not taken (yet): everything later on these qubits has to wait
-                if (blocked == all) break;
             }
-            if (best < 0) break;
-            const FusedOp &op = closed_[(size_t)best];
-            group.push_back(op);
-            hset |= op.qmask() & ~lowmask;
-            done[(size_t)best] = 1;
+            group.push_back(closed_[(size_t)pick.idx]);
+            hset |= qm[(size_t)pick.idx] & ~lowmask;
+            done[(size_t)pick.idx] = 1;
         }
         if (group.empty()) { // cannot happen while kmax >= 2; keep the scheduler total anyway
-            single_op_pass(closed_[first], out);
+            single_op_pass(closed_[first], sink);
             done[first] = 1;
         } else if (group.size() == 1) {
-            single_op_pass(group[0], out);
+            single_op_pass(group[0], sink);
         } else {
-            tile_pass(group, out);
+            tile_pass(group, sink);
         }
     }
 }

@@ -12,6 +12,7 @@
 
 #include <complex>
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 #include "qsim_internal.h"
@@ -57,8 +58,9 @@ struct SchedConfig {
     int tile_bits = 12;
     int tile_low_bits = 3;
     int tile_max_ops = 32;
-    int window = 4096; // clusters scanned ahead when grouping a pass
+    int window = 512;  // clusters scanned ahead when grouping a pass
     int merge = 1;     // level 3: merge neighbouring blocks of a pass into sparse <=3-qubit blocks
+    int rollout = 8;   // level 3: candidates tried (each by greedily finishing the pass) when a new qubit must be admitted; 0 = off
     int pad_from = 10; // first bit tried when unused tile slots are filled (below tile_low_bits: tile_low_bits)
 };
 
@@ -68,7 +70,11 @@ class Scheduler {
     void add_1q(const cd U[4], int q);
     void add_cx(int control, int target);
     void add_2q(const cd U[16], int q_hi, int q_lo);
-    // Closes every open cluster and appends the passes for everything added so far.
+    // Closes every open cluster and produces the passes for everything added so far, in launch order.  The sink
+    // form hands each pass over as soon as it is complete, so the caller can launch it while later passes are
+    // still being scheduled.
+    using PassSink = std::function<void(Pass &&)>;
+    void finish(const PassSink &sink);
     void finish(std::vector<Pass> &out);
     uint64_t gates_seen() const { return gates_; }
 
@@ -87,9 +93,9 @@ class Scheduler {
 
     void close(int idx);
     void fold_2q(const cd U[16], int q_hi, int q_lo, uint32_t gates);
-    void build_passes(std::vector<Pass> &out);
-    void single_op_pass(const FusedOp &op, std::vector<Pass> &out) const;
-    void tile_pass(const std::vector<FusedOp> &ops, std::vector<Pass> &out) const;
+    void build_passes(const PassSink &sink);
+    void single_op_pass(const FusedOp &op, const PassSink &sink) const;
+    void tile_pass(const std::vector<FusedOp> &ops, const PassSink &sink) const;
     void merge_sparse(std::vector<FusedOp> &ops) const;
 };
 

@@ -35,6 +35,7 @@ SCHED_CB = ctypes.CFUNCTYPE(None, c_void_p, c_int, c_int, c_int, POINTER(c_int),
 _DP = POINTER(c_double)
 SIGNATURES = {
     "qsim_device_count": (c_int, []),
+    "qsim_device_init": (c_int, [c_int]),
     "qsim_last_error": (c_char_p, []),
     "qsim_create": (c_int, [POINTER(c_void_p), c_int, c_int]),
     "qsim_create_external": (c_int, [POINTER(c_void_p), c_int, c_int, c_void_p]),

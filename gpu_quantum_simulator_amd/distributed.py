@@ -312,6 +312,9 @@ class ShardedSimulator:
                 ops.append(dist.P2POp(dist.irecv, rx[i], peer))
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+        if any(st[0] == "exchange" and len(st[1]) == self.p for st in self.plan.steps):
+            a = torch.zeros(self.world * 2, dtype=torch.float64, device=dev)
+            dist.all_to_all_single(torch.empty_like(a), a)
         if dev.type == "cuda":
             torch.cuda.synchronize()
         dist.barrier()
@@ -334,16 +337,22 @@ class ShardedSimulator:
         shard.sync()  # the pack ran on the engine's stream; the collective uses torch's
         mine, members = peers_of(self.rank, J)
         st, sc = shard.blocks(k)
-        ops = []
-        for b, peer in enumerate(members):
-            if b == mine:
-                st[b].copy_(sc[b])
-            else:
-                ops.append(dist.P2POp(dist.isend, sc[b], peer))
-                ops.append(dist.P2POp(dist.irecv, st[b], peer))
-                self.exchange_bytes += sc[b].numel() * 8
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+        if k == self.p and tuple(J) == tuple(range(self.p)):
+            # every rank takes part and member b IS rank b: one all-to-all collective (block b of the scratch goes to
+            # rank b, block b of the state comes from rank b) — RCCL drives all P-1 xGMI links at once
+            dist.all_to_all_single(st.view(-1), sc.view(-1))
+            self.exchange_bytes += (len(members) - 1) * sc[0].numel() * 8
+        else:
+            ops = []
+            for b, peer in enumerate(members):
+                if b == mine:
+                    st[b].copy_(sc[b])
+                else:
+                    ops.append(dist.P2POp(dist.isend, sc[b], peer))
+                    ops.append(dist.P2POp(dist.irecv, st[b], peer))
+                    self.exchange_bytes += sc[b].numel() * 8
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
         if st.is_cuda:
             shard.torch.cuda.current_stream().synchronize()
 

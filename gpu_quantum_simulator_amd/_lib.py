@@ -41,6 +41,7 @@ SIGNATURES = {
     "qsim_create_external": (c_int, [POINTER(c_void_p), c_int, c_int, c_void_p]),
     "qsim_destroy": (None, [c_void_p]),
     "qsim_reset": (c_int, [c_void_p]),
+    "qsim_reset_shard": (c_int, [c_void_p, c_int]),
     "qsim_num_qubits": (c_int, [c_void_p]),
     "qsim_set_option": (c_int, [c_void_p, c_int, c_long]),
     "qsim_get_option": (c_long, [c_void_p, c_int]),

@@ -298,10 +298,8 @@ extern "C" int qsim_cluster_set_option(qsim_cluster *c, int option, long value) 
 // Resets every shard to its part of |0...0> and the map to the identity.
 extern "C" int qsim_cluster_reset(qsim_cluster *c) {
     if (!c) return cfail(QSIM_ERR_ARG, "NULL cluster");
-    const double zero[2] = {0.0, 0.0};
     for (int r = 0; r < c->P; r++) {
-        int rc = qsim_reset(c->shard[r]);
-        if (rc == QSIM_OK && r != 0) rc = qsim_write(c->shard[r], 0, 1, zero);
+        const int rc = qsim_reset_shard(c->shard[r], r == 0);
         if (rc) return cfail(rc, "%s", qsim_last_error());
     }
     for (int q = 0; q < c->n; q++) c->pos[q] = q;

@@ -78,6 +78,8 @@ struct qsim_state {
     long max_pending = 1L << 16;
     // queue
     std::vector<QueuedGate> queue;
+    double zero_ket_amp = 1.0;     // amplitude at index 0 of the pending basis state (0: a shard that does not hold index 0)
+    bool zero_ket_pending = false; // |0...0> requested but not written yet (folded into the first tile pass if possible)
     // op ring for tile passes
     TileOp *d_ops = nullptr, *h_ops = nullptr;
     size_t ops_cap = 0, ops_used = 0;
@@ -263,16 +265,30 @@ static void account(qsim_state *s, int kclass, double bytes) {
     s->stats.k_bytes[kclass] += bytes;
 }
 
-extern "C" int qsim_reset(qsim_state *s) {
-    if (!s) return fail(QSIM_ERR_ARG, "NULL state");
-    HIP_TRY(hipSetDevice(s->device));
-    s->queue.clear();
+// Writes the pending |0...0> with the init kernel (when the next operation cannot generate it itself).
+static int materialize_zero_ket(qsim_state *s) {
+    if (!s->zero_ket_pending) return QSIM_OK;
+    s->zero_ket_pending = false;
     LaunchCfg cfg{s->stream, s->grid_cap};
     {
         LaunchScope scope(s, QSIM_K_INIT);
-        HIP_TRY(launch_init(cfg, s->amps, s->n));
+        HIP_TRY(launch_init(cfg, s->amps, s->n, s->zero_ket_amp));
     }
     account(s, QSIM_K_INIT, 16.0 * (double)(1ULL << s->n));
+    return QSIM_OK;
+}
+
+extern "C" int qsim_reset_shard(qsim_state *s, int holds_index0);
+extern "C" int qsim_reset(qsim_state *s) { return qsim_reset_shard(s, 1); }
+
+extern "C" int qsim_reset_shard(qsim_state *s, int holds_index0) {
+    if (!s) return fail(QSIM_ERR_ARG, "NULL state");
+    HIP_TRY(hipSetDevice(s->device));
+    s->queue.clear();
+    s->zero_ket_amp = holds_index0 ? 1.0 : 0.0;
+    // |0...0> is not written here: if the first pass after the reset is a tile pass it generates the state in LDS
+    // (one write of the state instead of write + read + write); anything else materialises it first.
+    s->zero_ket_pending = true;
     return QSIM_OK;
 }
 
@@ -398,6 +414,12 @@ static bool to_tile_op(const TileGeom &g, const FusedOp &op, TileOp &t) {
 }
 
 static int launch_pass(qsim_state *s, const Pass &p) {
+    const bool from_zero_ket = s->zero_ket_pending && p.kclass == QSIM_K_TILE;
+    if (s->zero_ket_pending && !from_zero_ket) {
+        const int rc = materialize_zero_ket(s);
+        if (rc) return rc;
+    }
+    s->zero_ket_pending = false;
     LaunchCfg cfg{s->stream, s->grid_cap};
     const FusedOp &op = p.ops[0];
     hipError_t e = hipSuccess;
@@ -448,13 +470,13 @@ static int launch_pass(qsim_state *s, const Pass &p) {
         for (int j = 0; j < p.geom.n_high; j++) hm |= 1ULL << p.geom.high[j];
         LaunchScope scope(s, p.kclass, (int)need, hm);
         const int threads = s->tile_threads; // 0: default for the tile size
-        e = launch_tile(cfg, s->amps, p.geom, d, (int)need, threads);
+        e = launch_tile(cfg, s->amps, p.geom, d, (int)need, threads, from_zero_ket, s->zero_ket_amp);
         break;
     }
     default: return fail(QSIM_ERR_ARG, "internal: unknown kernel class %d", p.kclass);
     }
     if (e != hipSuccess) return fail(QSIM_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
-    account(s, p.kclass, p.bytes);
+    account(s, p.kclass, from_zero_ket ? p.bytes / 2 : p.bytes); // a generating pass only writes
     return QSIM_OK;
 }
 
@@ -479,7 +501,8 @@ extern "C" int qsim_flush(qsim_state *s) {
 }
 
 extern "C" int qsim_sync(qsim_state *s) {
-    const int rc = qsim_flush(s);
+    int rc = qsim_flush(s);
+    if (rc == QSIM_OK) rc = materialize_zero_ket(s); // nothing consumed the pending |0...0>: write it now
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
     return QSIM_OK;
@@ -508,7 +531,8 @@ extern "C" int qsim_write(qsim_state *s, uint64_t first, uint64_t count, const d
 
 extern "C" int qsim_norm2(qsim_state *s, double *out) {
     if (!s || !out) return fail(QSIM_ERR_ARG, "NULL argument");
-    const int rc = qsim_flush(s);
+    int rc = qsim_flush(s);
+    if (rc == QSIM_OK) rc = materialize_zero_ket(s);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(s->d_scalar, 0, 8, s->stream));
     LaunchCfg cfg{s->stream, s->grid_cap};
@@ -537,6 +561,7 @@ extern "C" void qsim_putb(long long n, int len, char *buf) { // putb, quantum_si
 extern "C" int qsim_sample(qsim_state *s, const double *randoms, long shots, uint64_t *out) {
     if (!s || (shots > 0 && (!randoms || !out))) return fail(QSIM_ERR_ARG, "NULL argument");
     int rc = qsim_flush(s);
+    if (rc == QSIM_OK) rc = materialize_zero_ket(s);
     if (rc) return rc;
     constexpr int kBlockBits = 12;
     const uint64_t N = 1ULL << s->n;
@@ -590,7 +615,8 @@ extern "C" int qsim_pack_bits(qsim_state *s, const int *bits, int nbits, void *d
         if (bits[j] < 0 || bits[j] >= s->n || (j && bits[j] <= bits[j - 1]))
             return fail(QSIM_ERR_ARG, "pack: bit positions must be ascending and inside the shard");
     if (dst == (void *)s->amps) return fail(QSIM_ERR_ARG, "pack: dst must not alias the state");
-    const int rc = qsim_flush(s);
+    int rc = qsim_flush(s);
+    if (rc == QSIM_OK) rc = materialize_zero_ket(s);
     if (rc) return rc;
     LaunchCfg cfg{s->stream, s->grid_cap};
     hipError_t e;

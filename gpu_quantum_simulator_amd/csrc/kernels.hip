@@ -54,10 +54,10 @@ __device__ __forceinline__ amp_t shfl_xor2(amp_t a, int mask) {
 
 // ---------------------------------------------------------------------------------------------------
 // |0...0>
-__global__ __launch_bounds__(TPB) void k_init(amp_t *__restrict__ v, uint64_t N) {
+__global__ __launch_bounds__(TPB) void k_init(amp_t *__restrict__ v, uint64_t N, double amp0) {
     const uint64_t stride = (uint64_t)gridDim.x * TPB;
     for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < N; i += stride)
-        v[i] = amp_t{i == 0 ? 1.0 : 0.0, 0.0};
+        v[i] = amp_t{i == 0 ? amp0 : 0.0, 0.0};
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -248,6 +248,8 @@ __global__ __launch_bounds__(TPB) void k_gate2_hh(amp_t *__restrict__ v, uint64_
 // Geometry as the kernel sees it: the high tile bits as a mask (no runtime-indexed arrays in device code).
 struct TileDev {
     int32_t tile_bits, low_bits, n_high, n;
+    int32_t from_zero_ket, pad; // 1: the state is a basis state that has not been written yet: generate it, do not load it
+    double amp0;                // its amplitude at index 0 (1 for |0...0>, 0 for a shard that does not hold index 0)
     uint64_t high_mask; // global bit positions of tile-local bits L..B-1
 };
 
@@ -379,7 +381,13 @@ __global__ __launch_bounds__(THREADS) void k_tile(amp_t *__restrict__ v, TileDev
     auto next_base = [&](uint64_t b) { return ((b | ~outer_mask) + 1ULL) & outer_mask; }; // +1 scattered over the outer bits
 
     amp_t pf[APT];
+    const bool generate = g.from_zero_ket != 0; // wave-uniform
     auto fetch = [&](uint64_t tb) {
+        if (generate) { // |0...0>: amplitude 1 at global index 0 (tile base 0, slot 0), nothing to read
+#pragma unroll
+            for (int k = 0; k < APT; k++) pf[k] = amp_t{(tb == 0 && k == 0 && tid == 0) ? g.amp0 : 0.0, 0.0};
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < APT; k++) {
             const uint32_t e = tid + k * THREADS;
@@ -610,11 +618,11 @@ static inline unsigned grid_for(const LaunchCfg &cfg, uint64_t ntiles) {
     return (unsigned)(g ? g : 1);
 }
 
-hipError_t launch_init(const LaunchCfg &cfg, double2 *v, int n) {
+hipError_t launch_init(const LaunchCfg &cfg, double2 *v, int n, double amp0) {
     const uint64_t N = 1ULL << n;
     uint64_t blocks = ceil_div(N, TPB);
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(k_init, dim3((unsigned)blocks), dim3(TPB), 0, cfg.stream, (amp_t *)v, N);
+    hipLaunchKernelGGL(k_init, dim3((unsigned)blocks), dim3(TPB), 0, cfg.stream, (amp_t *)v, N, amp0);
     return hipGetLastError();
 }
 
@@ -671,7 +679,8 @@ hipError_t launch_gate2(const LaunchCfg &cfg, double2 *v, int n, int q_hi, int q
 int tile_lds_bytes(int tile_bits, int n_high) { return (16 << tile_bits) + (8 << n_high); }
 
 template <int B, int THREADS>
-static hipError_t launch_tile_t(const LaunchCfg &cfg, double2 *v, const TileGeom &g, const TileOp *d_ops, int n_ops) {
+static hipError_t launch_tile_t(const LaunchCfg &cfg, double2 *v, const TileGeom &g, const TileOp *d_ops, int n_ops,
+                                bool from_zero_ket, double amp0) {
     const uint64_t ntiles = 1ULL << (g.n - g.tile_bits);
     const int lds = tile_lds_bytes(g.tile_bits, g.n_high);
     static bool attr_set = false;
@@ -683,6 +692,9 @@ static hipError_t launch_tile_t(const LaunchCfg &cfg, double2 *v, const TileGeom
     }
     TileDev td;
     td.tile_bits = g.tile_bits; td.low_bits = g.low_bits; td.n_high = g.n_high; td.n = g.n;
+    td.from_zero_ket = from_zero_ket ? 1 : 0;
+    td.pad = 0;
+    td.amp0 = amp0;
     td.high_mask = 0;
     for (int j = 0; j < g.n_high; j++) td.high_mask |= 1ULL << g.high[j];
     // tiles per workgroup: enough to amortise the exposed first load, few enough to keep >= 8 workgroups per CU slot
@@ -697,27 +709,28 @@ static hipError_t launch_tile_t(const LaunchCfg &cfg, double2 *v, const TileGeom
 
 // threads: 0 = the default for the tile size.  Tiles below 2^8 amplitudes (tiny registers) use the 2^8 kernel's
 // tail guards with a smaller E, so every size from 1 to 13 bits has an instantiation.
-hipError_t launch_tile(const LaunchCfg &cfg, double2 *v, const TileGeom &g, const TileOp *d_ops, int n_ops, int threads) {
+hipError_t launch_tile(const LaunchCfg &cfg, double2 *v, const TileGeom &g, const TileOp *d_ops, int n_ops, int threads,
+                       bool from_zero_ket, double amp0) {
     switch (g.tile_bits) {
-    case 0: return launch_tile_t<0, 64>(cfg, v, g, d_ops, n_ops);
-    case 1: return launch_tile_t<1, 64>(cfg, v, g, d_ops, n_ops);
-    case 2: return launch_tile_t<2, 64>(cfg, v, g, d_ops, n_ops);
-    case 3: return launch_tile_t<3, 64>(cfg, v, g, d_ops, n_ops);
-    case 4: return launch_tile_t<4, 64>(cfg, v, g, d_ops, n_ops);
-    case 5: return launch_tile_t<5, 64>(cfg, v, g, d_ops, n_ops);
-    case 6: return launch_tile_t<6, 64>(cfg, v, g, d_ops, n_ops);
-    case 7: return launch_tile_t<7, 64>(cfg, v, g, d_ops, n_ops);
-    case 8: return launch_tile_t<8, 64>(cfg, v, g, d_ops, n_ops);
-    case 9: return launch_tile_t<9, 128>(cfg, v, g, d_ops, n_ops);
-    case 10: return threads == 512 ? launch_tile_t<10, 512>(cfg, v, g, d_ops, n_ops) : launch_tile_t<10, 256>(cfg, v, g, d_ops, n_ops);
-    case 11: return threads == 512 ? launch_tile_t<11, 512>(cfg, v, g, d_ops, n_ops) : launch_tile_t<11, 256>(cfg, v, g, d_ops, n_ops);
+    case 0: return launch_tile_t<0, 64>(cfg, v, g, d_ops, n_ops, from_zero_ket, amp0);
+    case 1: return launch_tile_t<1, 64>(cfg, v, g, d_ops, n_ops, from_zero_ket, amp0);
+    case 2: return launch_tile_t<2, 64>(cfg, v, g, d_ops, n_ops, from_zero_ket, amp0);
+    case 3: return launch_tile_t<3, 64>(cfg, v, g, d_ops, n_ops, from_zero_ket, amp0);
+    case 4: return launch_tile_t<4, 64>(cfg, v, g, d_ops, n_ops, from_zero_ket, amp0);
+    case 5: return launch_tile_t<5, 64>(cfg, v, g, d_ops, n_ops, from_zero_ket, amp0);
+    case 6: return launch_tile_t<6, 64>(cfg, v, g, d_ops, n_ops, from_zero_ket, amp0);
+    case 7: return launch_tile_t<7, 64>(cfg, v, g, d_ops, n_ops, from_zero_ket, amp0);
+    case 8: return launch_tile_t<8, 64>(cfg, v, g, d_ops, n_ops, from_zero_ket, amp0);
+    case 9: return launch_tile_t<9, 128>(cfg, v, g, d_ops, n_ops, from_zero_ket, amp0);
+    case 10: return threads == 512 ? launch_tile_t<10, 512>(cfg, v, g, d_ops, n_ops, from_zero_ket, amp0) : launch_tile_t<10, 256>(cfg, v, g, d_ops, n_ops, from_zero_ket, amp0);
+    case 11: return threads == 512 ? launch_tile_t<11, 512>(cfg, v, g, d_ops, n_ops, from_zero_ket, amp0) : launch_tile_t<11, 256>(cfg, v, g, d_ops, n_ops, from_zero_ket, amp0);
     case 12:
-        if (threads == 256) return launch_tile_t<12, 256>(cfg, v, g, d_ops, n_ops);
-        if (threads == 1024) return launch_tile_t<12, 1024>(cfg, v, g, d_ops, n_ops);
-        return launch_tile_t<12, 512>(cfg, v, g, d_ops, n_ops);
+        if (threads == 256) return launch_tile_t<12, 256>(cfg, v, g, d_ops, n_ops, from_zero_ket, amp0);
+        if (threads == 1024) return launch_tile_t<12, 1024>(cfg, v, g, d_ops, n_ops, from_zero_ket, amp0);
+        return launch_tile_t<12, 512>(cfg, v, g, d_ops, n_ops, from_zero_ket, amp0);
     case 13:
-        if (threads == 512) return launch_tile_t<13, 512>(cfg, v, g, d_ops, n_ops);
-        return launch_tile_t<13, 1024>(cfg, v, g, d_ops, n_ops);
+        if (threads == 512) return launch_tile_t<13, 512>(cfg, v, g, d_ops, n_ops, from_zero_ket, amp0);
+        return launch_tile_t<13, 1024>(cfg, v, g, d_ops, n_ops, from_zero_ket, amp0);
     default: return hipErrorInvalidValue;
     }
 }

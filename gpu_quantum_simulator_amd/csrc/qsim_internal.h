@@ -57,14 +57,16 @@ struct LaunchCfg {
 };
 
 // All launchers are asynchronous on cfg.stream and return the hipError_t of the launch.
-hipError_t launch_init(const LaunchCfg &cfg, double2 *v, int n);
+hipError_t launch_init(const LaunchCfg &cfg, double2 *v, int n, double amp0 = 1.0);
 hipError_t launch_gate1(const LaunchCfg &cfg, double2 *v, int n, int q, const M2 &U);
 hipError_t launch_phase(const LaunchCfg &cfg, double2 *v, int n, int q, double lr, double li);
 hipError_t launch_diag1_full(const LaunchCfg &cfg, double2 *v, int n, int q, double d0r, double d0i, double d1r,
                              double d1i);
 hipError_t launch_cx(const LaunchCfg &cfg, double2 *v, int n, int control, int target);
 hipError_t launch_gate2(const LaunchCfg &cfg, double2 *v, int n, int q_hi, int q_lo, const M4 &U);
-hipError_t launch_tile(const LaunchCfg &cfg, double2 *v, const TileGeom &g, const TileOp *d_ops, int n_ops, int threads);
+// from_zero_ket: the state is a not-yet-written |0...0>; the pass generates it in LDS instead of loading it
+hipError_t launch_tile(const LaunchCfg &cfg, double2 *v, const TileGeom &g, const TileOp *d_ops, int n_ops, int threads,
+                       bool from_zero_ket, double amp0 = 1.0);
 hipError_t launch_norm2(const LaunchCfg &cfg, const double2 *v, int n, double *d_out /* zeroed */);
 // d_out[b] = sum of |a|^2 over amplitudes [b << block_bits, (b+1) << block_bits), fixed summation order
 hipError_t launch_block_prob(const LaunchCfg &cfg, const double2 *v, int n, int block_bits, double *d_out);

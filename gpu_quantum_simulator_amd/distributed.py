@@ -232,11 +232,7 @@ class HipShard:
     # addresses are shared process-wide, so kernels work on them directly, but host<->device copies and
     # stream ordering stay with the runtime that owns the allocation.  Hand-offs are host-side syncs.
     def reset(self, holds_index0: bool):
-        self.sim.reset()
-        if not holds_index0:
-            self.sim.sync()
-            self.state[0].zero_()
-            self.torch.cuda.current_stream().synchronize()
+        self.sim.reset(holds_index0)
 
     def apply_local(self, key: int):
         self.sim.run(self._compiled[key])

@@ -163,8 +163,8 @@ class Simulator:
     def set_option(self, opt: int, value: int) -> None:
         check(_lib.load().qsim_set_option(self._h, opt, value))
 
-    def reset(self) -> None:
-        check(_lib.load().qsim_reset(self._h))
+    def reset(self, holds_index0: bool = True) -> None:
+        check(_lib.load().qsim_reset_shard(self._h, 1 if holds_index0 else 0))
 
     def close(self) -> None:
         if self._h:

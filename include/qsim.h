@@ -96,7 +96,11 @@ int qsim_create(qsim_state **out, int num_q, int device);
 /* Same, on caller-owned device memory of 16<<num_q bytes (e.g. a torch tensor's storage). */
 int qsim_create_external(qsim_state **out, int num_q, int device, void *device_amps);
 void qsim_destroy(qsim_state *s);
-int qsim_reset(qsim_state *s); /* back to |0...0>; drops queued gates */
+int qsim_reset(qsim_state *s); /* back to |0...0>; drops queued gates.  Lazy: written by the first pass that can
+                                 * generate it in LDS, or by the init kernel when anything else comes first */
+/* Same for one shard of a larger register: holds_index0 = 0 gives the all-zero vector (the shard does not contain
+ * basis index 0). */
+int qsim_reset_shard(qsim_state *s, int holds_index0);
 int qsim_num_qubits(const qsim_state *s);
 int qsim_set_option(qsim_state *s, int option, long value);
 long qsim_get_option(const qsim_state *s, int option);

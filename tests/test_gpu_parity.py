@@ -478,3 +478,42 @@ def test_cli_sharded(oracle, golden_dir, tmp_path):
     assert p.returncode == 0 and len(p.stdout.splitlines()) == 1 and '"shards": 4' in p.stderr
     want = np.load(os.path.join(golden_dir, "rand_n12_all.npy")).view(np.complex128).reshape(-1)
     assert np.max(np.abs(np.fromfile(dump, dtype=np.complex128) - want)) < TOL
+
+
+def test_edge_cases_empty_tiny_and_auto_flush(oracle, tmp_path):
+    hdr = 'OPENQASM 3.0;\ninclude "stdgates.inc";\n'
+    # empty circuit: |0...0> untouched (and the lazily written state is materialised by the read)
+    p = tmp_path / "empty.qasm"
+    p.write_text(hdr + "qubit[5] q;\n")
+    a = run_qasm(str(p))
+    assert a[0] == 1 and not a[1:].any()
+    # one-qubit register, every fuse level
+    p = tmp_path / "one.qasm"
+    p.write_text(hdr + "qubit[1] q;\nh q[0];\nt q[0];\nsx q[0];\nrz(0.37) q[0];\nx q[0];\n")
+    _, want, _, _ = oracle.run_qasm(str(p))
+    for fuse in (0, 1, 2, 3):
+        assert np.max(np.abs(run_qasm(str(p), fuse=fuse) - want)) < TOL
+    # zero-qubit register: a single amplitude
+    with Simulator(0) as sim:
+        assert sim.read()[0] == 1
+    # long circuit with a tiny pending queue: many automatic flushes, options changed mid-stream
+    n = 15
+    gates = circuits.random_gates(n, 3000, 123, "all")
+    path = circuits.write_qasm(str(tmp_path / "long.qasm"), n, gates)
+    _, want, _, _ = oracle.run_qasm(path)
+    c = Circuit.from_file(path)
+    with Simulator(n, max_pending=37) as sim:
+        sim.run(c, 0, 1000)
+        sim.set_option(_lib.OPT_FUSE, 1)
+        sim.run(c, 1000, 1000)
+        sim.set_option(_lib.OPT_FUSE, 3)
+        sim.set_option(_lib.OPT_TILE_BITS, 9)
+        sim.run(c, 2000, -1)
+        assert np.max(np.abs(sim.read() - want)) < TOL
+        assert sim.stats()["gates"] == 3000
+    # reset in the middle of queued work drops it
+    with Simulator(6) as sim:
+        sim.apply_1q(gate_matrix("h"), 3)
+        sim.reset()
+        a = sim.read()
+        assert a[0] == 1 and not a[1:].any()

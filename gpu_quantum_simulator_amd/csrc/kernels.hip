@@ -273,7 +273,10 @@ typedef const TileOp __attribute__((address_space(4))) *ConstOps;
 __device__ __forceinline__ uint32_t ins0(uint32_t x, uint32_t himask) { return x + (x & himask); }
 
 // Generic sparse block (TOP_SP): K qubits, T entries per row, all loop bounds static.
-template <int B, int THREADS, int K, int T>
+// SKIPS = false is the branch-free form for blocks without identity rows: one basic block, so the compiler can hoist
+// the next rows' scalar loads and LDS reads above the current row's arithmetic (with the per-row skip branch every
+// row is its own latency chain: s_load -> ds_read -> FMA).
+template <int B, int THREADS, int K, int T, bool SKIPS>
 __device__ __forceinline__ void tile_op_sparse(amp_t *lds, ConstOps ops, int oi, uint32_t tid) {
     constexpr uint32_t E = 1u << B;
     constexpr int R = 1 << K;
@@ -294,7 +297,7 @@ __device__ __forceinline__ void tile_op_sparse(amp_t *lds, ConstOps ops, int oi,
     amp_t y[GPT][R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        if ((skip >> r) & 1u) continue; // wave-uniform; everything below is straight-line per row
+        if (SKIPS && ((skip >> r) & 1u)) continue; // wave-uniform; everything below is straight-line per row
         uint32_t off[T];
         double cr[T], ci[T];
 #pragma unroll
@@ -321,7 +324,7 @@ __device__ __forceinline__ void tile_op_sparse(amp_t *lds, ConstOps ops, int oi,
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        if ((skip >> r) & 1u) continue;
+        if (SKIPS && ((skip >> r) & 1u)) continue;
         const uint32_t off = ops[oi].rowoff[r];
 #pragma unroll
         for (int g = 0; g < GPT; g++)
@@ -407,13 +410,14 @@ __global__ __launch_bounds__(THREADS) void k_tile(amp_t *__restrict__ v, TileDev
             const int kind = ops[oi].kind;
             if (kind == TOP_SP) {
                 const int nq = ops[oi].nq, terms = ops[oi].terms;
+                const bool skips = ops[oi].meta != 0;
                 if (nq == 2) {
-                    if (terms == 1) tile_op_sparse<B, THREADS, 2, 1>(lds, ops, oi, tid);
-                    else tile_op_sparse<B, THREADS, 2, 2>(lds, ops, oi, tid);
+                    if (terms == 1) { if (skips) tile_op_sparse<B, THREADS, 2, 1, true>(lds, ops, oi, tid); else tile_op_sparse<B, THREADS, 2, 1, false>(lds, ops, oi, tid); }
+                    else { if (skips) tile_op_sparse<B, THREADS, 2, 2, true>(lds, ops, oi, tid); else tile_op_sparse<B, THREADS, 2, 2, false>(lds, ops, oi, tid); }
                 } else {
-                    if (terms == 1) tile_op_sparse<B, THREADS, 3, 1>(lds, ops, oi, tid);
-                    else if (terms == 2) tile_op_sparse<B, THREADS, 3, 2>(lds, ops, oi, tid);
-                    else tile_op_sparse<B, THREADS, 3, 4>(lds, ops, oi, tid);
+                    if (terms == 1) { if (skips) tile_op_sparse<B, THREADS, 3, 1, true>(lds, ops, oi, tid); else tile_op_sparse<B, THREADS, 3, 1, false>(lds, ops, oi, tid); }
+                    else if (terms == 2) { if (skips) tile_op_sparse<B, THREADS, 3, 2, true>(lds, ops, oi, tid); else tile_op_sparse<B, THREADS, 3, 2, false>(lds, ops, oi, tid); }
+                    else tile_op_sparse<B, THREADS, 3, 4, false>(lds, ops, oi, tid); // a 4-entry row is never an identity row
                 }
             } else if (kind == TOP_G2) {
                 const uint32_t bl = (uint32_t)ops[oi].b[0], bh = (uint32_t)ops[oi].b[1];

@@ -392,10 +392,13 @@ static bool to_tile_op(const TileGeom &g, const FusedOp &op, TileOp &t) {
     const int T = maxnnz <= 1 ? 1 : maxnnz <= 2 ? 2 : 4;
     t.kind = TOP_SP;
     t.terms = T;
-    auto slot_off = [&](int code) { // LDS index offset of a slot code: bit a of the code sits at tile-local bit b[a]
+    // LDS BYTE offset of a slot code (bit a of the code sits at tile-local bit b[a]), already passed through the
+    // kernel's layout swizzle (kernels.hip sw_slot: unit bits 0..3 ^= slot bit 4; linear, so it commutes with the
+    // XOR the kernel combines it with)
+    auto slot_off = [&](int code) {
         uint32_t o = 0;
         for (int a = 0; a < k; a++) o |= (uint32_t)((code >> a) & 1) << t.b[a];
-        return o;
+        return o ^ (((o >> 4) & 1u) * 15u);
     };
     for (int r = 0; r < D; r++) {
         t.rowoff[r] = slot_off(r) * 16u;

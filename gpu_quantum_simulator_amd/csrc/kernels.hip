@@ -269,6 +269,16 @@ __device__ __forceinline__ uint64_t deposit(uint64_t x, uint64_t mask) {
 // loads (s_load_dwordx*): the matrix lives in SGPRs / the scalar cache, not in vector registers.
 typedef const TileOp __attribute__((address_space(4))) *ConstOps;
 
+// LDS layout swizzle of a tile slot index: slot bits 0..3 (the 16-byte unit inside a 256-byte bank row) are XORed
+// with slot bit 4.  An op on tile-local bit h <= 3 makes 16 consecutive lanes touch the slots whose bit h is fixed:
+// unswizzled they fall on 8 of the 16 units (2-way bank conflict on every ds_read/ds_write_b128, 29 % of all LDS
+// cycles on the bench circuit); with the parity column added any four of the slot bits 0..4 map to independent unit
+// bits, so all single-hole patterns are conflict-free.  The map is linear over XOR: sw(a | b) = sw(a) ^ sw(b) for
+// disjoint a, b, so per-thread bases are swizzled once and the wave-uniform operand offsets arrive pre-swizzled
+// from the host (TileOp::off / rowoff) — no extra instruction per access.
+__device__ __forceinline__ uint32_t sw_slot(uint32_t slot) { return slot ^ (((slot >> 4) & 1u) * 15u); }
+__device__ __forceinline__ uint32_t sw_byte(uint32_t byte) { return byte ^ (((byte >> 8) & 1u) * 0xF0u); }
+
 // Index of the k-th work item with a zero inserted at bit b (b wave-uniform): x + (x & ~((1<<b)-1)).
 __device__ __forceinline__ uint32_t ins0(uint32_t x, uint32_t himask) { return x + (x & himask); }
 
@@ -292,7 +302,7 @@ __device__ __forceinline__ void tile_op_sparse(amp_t *lds, ConstOps ops, int oi,
         uint32_t x = ins0(tid + g * THREADS, ~((1u << b0) - 1u));
         if (K >= 2) x = ins0(x, ~((1u << b1) - 1u));
         if (K >= 3) x = ins0(x, ~((1u << b2) - 1u));
-        base[g] = x << 4;
+        base[g] = sw_byte(x << 4);
     }
     amp_t y[GPT][R];
 #pragma unroll
@@ -312,7 +322,7 @@ __device__ __forceinline__ void tile_op_sparse(amp_t *lds, ConstOps ops, int oi,
         for (int g = 0; g < GPT; g++)
 #pragma unroll
             for (int j = 0; j < T; j++)
-                if (FULL || tid + g * THREADS < NG) x[g][j] = *reinterpret_cast<amp_t *>(ldsb + (base[g] | off[j])); // T reads in flight
+                if (FULL || tid + g * THREADS < NG) x[g][j] = *reinterpret_cast<amp_t *>(ldsb + (base[g] ^ off[j])); // T reads in flight
 #pragma unroll
         for (int g = 0; g < GPT; g++)
             if (FULL || tid + g * THREADS < NG) {
@@ -328,7 +338,7 @@ __device__ __forceinline__ void tile_op_sparse(amp_t *lds, ConstOps ops, int oi,
         const uint32_t off = ops[oi].rowoff[r];
 #pragma unroll
         for (int g = 0; g < GPT; g++)
-            if (FULL || tid + g * THREADS < NG) *reinterpret_cast<amp_t *>(ldsb + (base[g] | off)) = y[g][r];
+            if (FULL || tid + g * THREADS < NG) *reinterpret_cast<amp_t *>(ldsb + (base[g] ^ off)) = y[g][r];
     }
 }
 
@@ -348,6 +358,7 @@ __global__ __launch_bounds__(THREADS) void k_tile(amp_t *__restrict__ v, TileDev
     uint64_t *hoff = reinterpret_cast<uint64_t *>(smem + ((size_t)16 << B));
     ConstOps ops = (ConstOps)(uintptr_t)ops_g;
     const uint32_t tid = threadIdx.x;
+    const uint32_t tid_sw = sw_slot(tid); // slot tid + k*THREADS swizzles to tid_sw + k*THREADS (THREADS is a multiple of 32)
     const uint32_t lowmask = (1u << L) - 1u;
     const uint64_t nmask = g.n >= 64 ? ~0ULL : ((1ULL << g.n) - 1ULL);
     const uint64_t outer_mask = nmask & ~(g.high_mask | (uint64_t)lowmask);
@@ -401,7 +412,7 @@ __global__ __launch_bounds__(THREADS) void k_tile(amp_t *__restrict__ v, TileDev
 #pragma unroll
         for (int k = 0; k < APT; k++) {
             const uint32_t e = tid + k * THREADS;
-            if (FULL || e < E) lds[e] = pf[k];
+            if (FULL || e < E) lds[tid_sw + k * THREADS] = pf[k];
         }
         __syncthreads();
         if (prefetch_next) fetch(next_base(base));
@@ -422,7 +433,7 @@ __global__ __launch_bounds__(THREADS) void k_tile(amp_t *__restrict__ v, TileDev
             } else if (kind == TOP_G2) {
                 const uint32_t bl = (uint32_t)ops[oi].b[0], bh = (uint32_t)ops[oi].b[1];
                 const uint32_t hm_lo = ~((1u << bl) - 1u), hm_hi = ~((1u << bh) - 1u);
-                const uint32_t o1 = 1u << bl, o2 = 1u << bh, o3 = o1 | o2;
+                const uint32_t o1 = sw_slot(1u << bl), o2 = sw_slot(1u << bh), o3 = o1 ^ o2; // wave-uniform
                 double ur[16], ui[16];
 #pragma unroll
                 for (int k = 0; k < 16; k++) { ur[k] = ops[oi].re[k]; ui[k] = ops[oi].im[k]; }
@@ -430,9 +441,9 @@ __global__ __launch_bounds__(THREADS) void k_tile(amp_t *__restrict__ v, TileDev
                 amp_t x[QPT][4];
 #pragma unroll
                 for (int k = 0; k < QPT; k++) {
-                    i00[k] = ins0(ins0(tid + k * THREADS, hm_lo), hm_hi);
+                    i00[k] = sw_slot(ins0(ins0(tid + k * THREADS, hm_lo), hm_hi));
                     if (FULL || tid + k * THREADS < E / 4) {
-                        x[k][0] = lds[i00[k]]; x[k][1] = lds[i00[k] | o1]; x[k][2] = lds[i00[k] | o2]; x[k][3] = lds[i00[k] | o3];
+                        x[k][0] = lds[i00[k]]; x[k][1] = lds[i00[k] ^ o1]; x[k][2] = lds[i00[k] ^ o2]; x[k][3] = lds[i00[k] ^ o3];
                     }
                 }
 #pragma unroll
@@ -447,46 +458,46 @@ __global__ __launch_bounds__(THREADS) void k_tile(amp_t *__restrict__ v, TileDev
                             acc = cfma(x[k][3], ur[4 * r + 3], ui[4 * r + 3], acc);
                             y[r] = acc;
                         }
-                        lds[i00[k]] = y[0]; lds[i00[k] | o1] = y[1]; lds[i00[k] | o2] = y[2]; lds[i00[k] | o3] = y[3];
+                        lds[i00[k]] = y[0]; lds[i00[k] ^ o1] = y[1]; lds[i00[k] ^ o2] = y[2]; lds[i00[k] ^ o3] = y[3];
                     }
             } else if (kind == TOP_G1) {
                 const uint32_t bh = (uint32_t)ops[oi].b[0];
-                const uint32_t hm = ~((1u << bh) - 1u), o1 = 1u << bh;
+                const uint32_t hm = ~((1u << bh) - 1u), o1 = sw_slot(1u << bh);
                 const double u0r = ops[oi].re[0], u0i = ops[oi].im[0], u1r = ops[oi].re[1], u1i = ops[oi].im[1];
                 const double u2r = ops[oi].re[2], u2i = ops[oi].im[2], u3r = ops[oi].re[3], u3i = ops[oi].im[3];
                 uint32_t i0[PPT];
                 amp_t a0[PPT], a1[PPT];
 #pragma unroll
                 for (int k = 0; k < PPT; k++) {
-                    i0[k] = ins0(tid + k * THREADS, hm);
-                    if (FULL || tid + k * THREADS < E / 2) { a0[k] = lds[i0[k]]; a1[k] = lds[i0[k] | o1]; }
+                    i0[k] = sw_slot(ins0(tid + k * THREADS, hm));
+                    if (FULL || tid + k * THREADS < E / 2) { a0[k] = lds[i0[k]]; a1[k] = lds[i0[k] ^ o1]; }
                 }
 #pragma unroll
                 for (int k = 0; k < PPT; k++)
                     if (FULL || tid + k * THREADS < E / 2) {
                         lds[i0[k]] = cfma(a1[k], u1r, u1i, cmul(a0[k], u0r, u0i));
-                        lds[i0[k] | o1] = cfma(a1[k], u3r, u3i, cmul(a0[k], u2r, u2i));
+                        lds[i0[k] ^ o1] = cfma(a1[k], u3r, u3i, cmul(a0[k], u2r, u2i));
                     }
             } else { // TOP_DIAG1
                 const uint32_t bh = (uint32_t)ops[oi].b[0];
-                const uint32_t hm = ~((1u << bh) - 1u), o1 = 1u << bh;
+                const uint32_t hm = ~((1u << bh) - 1u), o1 = sw_slot(1u << bh);
                 const double d0r = ops[oi].re[0], d0i = ops[oi].im[0], d1r = ops[oi].re[1], d1i = ops[oi].im[1];
                 const bool unit0 = ops[oi].meta & 1;
                 uint32_t i0[PPT];
                 amp_t a0[PPT], a1[PPT];
 #pragma unroll
                 for (int k = 0; k < PPT; k++) {
-                    i0[k] = ins0(tid + k * THREADS, hm);
+                    i0[k] = sw_slot(ins0(tid + k * THREADS, hm));
                     if (FULL || tid + k * THREADS < E / 2) {
                         if (!unit0) a0[k] = lds[i0[k]];
-                        a1[k] = lds[i0[k] | o1];
+                        a1[k] = lds[i0[k] ^ o1];
                     }
                 }
 #pragma unroll
                 for (int k = 0; k < PPT; k++)
                     if (FULL || tid + k * THREADS < E / 2) {
                         if (!unit0) lds[i0[k]] = cmul(a0[k], d0r, d0i);
-                        lds[i0[k] | o1] = cmul(a1[k], d1r, d1i);
+                        lds[i0[k] ^ o1] = cmul(a1[k], d1r, d1i);
                     }
             }
             __syncthreads();
@@ -496,7 +507,7 @@ __global__ __launch_bounds__(THREADS) void k_tile(amp_t *__restrict__ v, TileDev
 #pragma unroll
         for (int k = 0; k < APT; k++) {
             const uint32_t e = tid + k * THREADS;
-            if (FULL || e < E) *elem_ptr(base, k) = lds[e];
+            if (FULL || e < E) *elem_ptr(base, k) = lds[tid_sw + k * THREADS];
         }
         __syncthreads();
     };

@@ -279,6 +279,13 @@ typedef const TileOp __attribute__((address_space(4))) *ConstOps;
 __device__ __forceinline__ uint32_t sw_slot(uint32_t slot) { return slot ^ (((slot >> 4) & 1u) * 15u); }
 __device__ __forceinline__ uint32_t sw_byte(uint32_t byte) { return byte ^ (((byte >> 8) & 1u) * 0xF0u); }
 
+// LDS access by raw byte address.  k_tile has no static __shared__, so its dynamic LDS region starts at address 0
+// (AMDGPU ABI: dynamic LDS follows the static part) and a tile byte offset IS the LDS address; going through the
+// `extern __shared__` symbol instead costs one v_add_u32 (of a link-time zero) per access.
+typedef __attribute__((address_space(3))) amp_t lds_amp_t;
+__device__ __forceinline__ amp_t lds_load(uint32_t byte) { return *(lds_amp_t *)(uintptr_t)byte; }
+__device__ __forceinline__ void lds_store(uint32_t byte, amp_t v) { *(lds_amp_t *)(uintptr_t)byte = v; }
+
 // Index of the k-th work item with a zero inserted at bit b (b wave-uniform): x + (x & ~((1<<b)-1)).
 __device__ __forceinline__ uint32_t ins0(uint32_t x, uint32_t himask) { return x + (x & himask); }
 
@@ -295,8 +302,8 @@ __device__ __forceinline__ void tile_op_sparse(amp_t *lds, ConstOps ops, int oi,
     constexpr bool FULL = NG >= (uint32_t)THREADS && NG % THREADS == 0;
     const uint32_t b0 = (uint32_t)ops[oi].b[0], b1 = (uint32_t)ops[oi].b[1], b2 = (uint32_t)ops[oi].b[2];
     const uint32_t skip = (uint32_t)ops[oi].meta;
-    unsigned char *ldsb = reinterpret_cast<unsigned char *>(lds);
-    uint32_t base[GPT]; // BYTE address of the group's slot 0
+    (void)lds;
+    uint32_t base[GPT]; // LDS BYTE address of the group's slot 0 (swizzled)
 #pragma unroll
     for (int g = 0; g < GPT; g++) {
         uint32_t x = ins0(tid + g * THREADS, ~((1u << b0) - 1u));
@@ -322,7 +329,7 @@ __device__ __forceinline__ void tile_op_sparse(amp_t *lds, ConstOps ops, int oi,
         for (int g = 0; g < GPT; g++)
 #pragma unroll
             for (int j = 0; j < T; j++)
-                if (FULL || tid + g * THREADS < NG) x[g][j] = *reinterpret_cast<amp_t *>(ldsb + (base[g] ^ off[j])); // T reads in flight
+                if (FULL || tid + g * THREADS < NG) x[g][j] = lds_load(base[g] ^ off[j]); // T reads in flight
 #pragma unroll
         for (int g = 0; g < GPT; g++)
             if (FULL || tid + g * THREADS < NG) {
@@ -338,7 +345,7 @@ __device__ __forceinline__ void tile_op_sparse(amp_t *lds, ConstOps ops, int oi,
         const uint32_t off = ops[oi].rowoff[r];
 #pragma unroll
         for (int g = 0; g < GPT; g++)
-            if (FULL || tid + g * THREADS < NG) *reinterpret_cast<amp_t *>(ldsb + (base[g] ^ off)) = y[g][r];
+            if (FULL || tid + g * THREADS < NG) lds_store(base[g] ^ off, y[g][r]);
     }
 }
 

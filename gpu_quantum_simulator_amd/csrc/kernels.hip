@@ -370,6 +370,10 @@ __global__ __launch_bounds__(THREADS) void k_tile(amp_t *__restrict__ v, TileDev
     const uint64_t nmask = g.n >= 64 ? ~0ULL : ((1ULL << g.n) - 1ULL);
     const uint64_t outer_mask = nmask & ~(g.high_mask | (uint64_t)lowmask);
 
+    // lds_load / lds_store address the tile by raw LDS byte address: that is only right while this kernel's dynamic
+    // LDS region starts at 0, i.e. while nobody adds a static __shared__ array to it.  Fail loudly otherwise.
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
+
     for (uint32_t j = tid; j < (1u << H); j += THREADS) hoff[j] = deposit(j, g.high_mask);
     __syncthreads();
 

@@ -268,6 +268,7 @@ static void account(qsim_state *s, int kclass, double bytes) {
 // Writes the pending |0...0> with the init kernel (when the next operation cannot generate it itself).
 static int materialize_zero_ket(qsim_state *s) {
     if (!s->zero_ket_pending) return QSIM_OK;
+    HIP_TRY(hipSetDevice(s->device)); // a cluster drives several devices from one thread
     s->zero_ket_pending = false;
     LaunchCfg cfg{s->stream, s->grid_cap};
     {
@@ -518,6 +519,7 @@ extern "C" int qsim_read(qsim_state *s, uint64_t first, uint64_t count, double *
     if (first > N || count > N - first) return fail(QSIM_ERR_ARG, "read range outside the state");
     const int rc = qsim_sync(s);
     if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->device));
     if (count) HIP_TRY(hipMemcpy(out, s->amps + first, count * 16, hipMemcpyDeviceToHost));
     return QSIM_OK;
 }
@@ -528,6 +530,7 @@ extern "C" int qsim_write(qsim_state *s, uint64_t first, uint64_t count, const d
     if (first > N || count > N - first) return fail(QSIM_ERR_ARG, "write range outside the state");
     const int rc = qsim_sync(s);
     if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->device));
     if (count) HIP_TRY(hipMemcpy(s->amps + first, in, count * 16, hipMemcpyHostToDevice));
     return QSIM_OK;
 }
@@ -537,6 +540,7 @@ extern "C" int qsim_norm2(qsim_state *s, double *out) {
     int rc = qsim_flush(s);
     if (rc == QSIM_OK) rc = materialize_zero_ket(s);
     if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipMemsetAsync(s->d_scalar, 0, 8, s->stream));
     LaunchCfg cfg{s->stream, s->grid_cap};
     HIP_TRY(launch_norm2(cfg, s->amps, s->n, s->d_scalar));
@@ -566,6 +570,7 @@ extern "C" int qsim_sample(qsim_state *s, const double *randoms, long shots, uin
     int rc = qsim_flush(s);
     if (rc == QSIM_OK) rc = materialize_zero_ket(s);
     if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->device));
     constexpr int kBlockBits = 12;
     const uint64_t N = 1ULL << s->n;
     const int bb = s->n < kBlockBits ? s->n : kBlockBits;
@@ -621,6 +626,7 @@ extern "C" int qsim_pack_bits(qsim_state *s, const int *bits, int nbits, void *d
     int rc = qsim_flush(s);
     if (rc == QSIM_OK) rc = materialize_zero_ket(s);
     if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->device));
     LaunchCfg cfg{s->stream, s->grid_cap};
     hipError_t e;
     {

@@ -709,12 +709,15 @@ static hipError_t launch_tile_t(const LaunchCfg &cfg, double2 *v, const TileGeom
                                 bool from_zero_ket, double amp0) {
     const uint64_t ntiles = 1ULL << (g.n - g.tile_bits);
     const int lds = tile_lds_bytes(g.tile_bits, g.n_high);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the opt-in to more than 64 KiB of dynamic LDS is per device (a cluster drives several from one process)
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<B, THREADS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     TileDev td;
     td.tile_bits = g.tile_bits; td.low_bits = g.low_bits; td.n_high = g.n_high; td.n = g.n;

@@ -517,3 +517,31 @@ def test_edge_cases_empty_tiny_and_auto_flush(oracle, tmp_path):
         sim.reset()
         a = sim.read()
         assert a[0] == 1 and not a[1:].any()
+
+
+def test_randomised_geometry_sweep(oracle, tmp_path):
+    """Seeded sweep over register sizes, vocabularies and every engine option (tile size, low bits, ops per pass,
+    threads, padding start, grid cap): each case against the oracle.  Catches geometry corner cases (n just above the
+    tile size, tiles wider than the register, under-filled tiles) that the fixed cases above do not hit."""
+    rng = np.random.default_rng(20240117)
+    worst = 0.0
+    for case in range(60):
+        n = int(rng.integers(2, 21))
+        depth = int(rng.integers(20, 400))
+        vocab = "all" if rng.random() < 0.7 else "clifford_t"
+        tile_bits = int(rng.integers(8, 14))
+        tile_low = int(rng.integers(max(2, tile_bits - 10), min(6, tile_bits - 2) + 1))
+        opts = {"tile_bits": tile_bits, "tile_low_bits": tile_low, "tile_max_ops": int(rng.integers(1, 40)),
+                "tile_pad_from": int(rng.integers(-1, 20))}
+        if tile_bits >= 12 and rng.random() < 0.5:
+            opts["tile_threads"] = int(rng.choice([256, 512, 1024] if tile_bits == 12 else [512, 1024]))
+        if rng.random() < 0.3:
+            opts["grid_cap"] = int(rng.integers(1, 64))
+        fuse = int(rng.choice([0, 1, 2, 3, 3, 3]))
+        path = circuits.random_circuit_file(str(tmp_path / f"f{case}.qasm"), n, depth, 5000 + case, vocab)
+        _, want, _, _ = oracle.run_qasm(path)
+        got = run_qasm(path, fuse=fuse, **opts)
+        err = float(np.max(np.abs(got - want)))
+        assert err < TOL, (case, n, depth, vocab, fuse, opts, err)
+        worst = max(worst, err)
+    assert worst < 1e-12

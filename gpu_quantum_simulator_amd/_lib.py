@@ -31,6 +31,8 @@ class QsimStats(ctypes.Structure):
 
 SCHED_CB = ctypes.CFUNCTYPE(None, c_void_p, c_int, c_int, c_int, POINTER(c_int), c_int, POINTER(c_double), c_int)
 
+LOCAL_OP_CB = ctypes.CFUNCTYPE(None, c_void_p, c_int, c_int, c_int, POINTER(c_double))
+
 # every symbol include/qsim.h declares: name -> (restype, argtypes)
 _DP = POINTER(c_double)
 SIGNATURES = {
@@ -72,7 +74,13 @@ SIGNATURES = {
     "qsim_cluster_norm2": (c_int, [c_void_p, _DP]),
     "qsim_cluster_exchange_stats": (c_int, [c_void_p, POINTER(c_uint64), _DP]),
     "qsim_cluster_error": (c_char_p, []),
-    "qsim_plan_shards": (c_long, [c_void_p, c_int, POINTER(c_int), c_long, POINTER(c_int), POINTER(c_int)]),
+    "qsim_shard_plan_create": (c_int, [POINTER(c_void_p), c_void_p, c_int]),
+    "qsim_shard_plan_free": (None, [c_void_p]),
+    "qsim_shard_plan_num_steps": (c_int, [c_void_p]),
+    "qsim_shard_plan_step": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "qsim_shard_plan_final_pos": (c_int, [c_void_p, POINTER(c_int)]),
+    "qsim_shard_plan_local_ops": (c_int, [c_void_p, c_int, c_int, LOCAL_OP_CB, c_void_p]),
+    "qsim_shard_plan_apply_local": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "qsim_get_stats": (c_int, [c_void_p, POINTER(QsimStats)]),
     "qsim_reset_stats": (c_int, [c_void_p]),
     "qsim_launch_log": (c_long, [c_void_p, c_long, POINTER(c_int), POINTER(c_int), POINTER(c_uint64), POINTER(c_double)]),

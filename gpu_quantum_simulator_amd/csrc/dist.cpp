@@ -448,32 +448,79 @@ extern "C" int qsim_cluster_exchange_stats(const qsim_cluster *c, uint64_t *exch
     return QSIM_OK;
 }
 
-// Host-only: the exchange sequence and final map the planner produces (tests compare it with distributed.ShardPlan).
-// steps_out receives, per exchange, k followed by k shard-id bits and k local positions; returns the number of ints
-// written (or needed, when cap is too small), -1 on error.
-extern "C" long qsim_plan_shards(const qsim_circuit *circ, int num_shards, int *steps_out, long cap, int *final_pos,
-                                 int *n_local_steps) {
-    if (!circ) return -1;
+// ---- the plan as an object (host only): what distributed.py's one-process-per-GPU driver executes -------------
+struct qsim_shard_plan {
+    Plan plan;
+    int P = 0;
+};
+
+extern "C" int qsim_shard_plan_create(qsim_shard_plan **out, const qsim_circuit *circ, int num_shards) {
+    if (!out || !circ) return cfail(QSIM_ERR_ARG, "NULL argument");
+    *out = nullptr;
     int p = 0;
     while ((1 << p) < num_shards) p++;
-    if ((1 << p) != num_shards || (p > 0 && circ->num_q - p < 2)) return -1;
+    if (num_shards < 1 || (1 << p) != num_shards) return cfail(QSIM_ERR_ARG, "shard count %d is not a power of two", num_shards);
+    if (p > 0 && circ->num_q - p < 2) return cfail(QSIM_ERR_ARG, "%d qubits cannot be split over %d shards", circ->num_q, num_shards);
+    for (long i = 0; i < circ->count; i++)
+        if (circ->gates[i].kind == QSIM_GATE_U2) return cfail(QSIM_ERR_ARG, "generic 2-qubit gates are not supported on shards");
     std::vector<LGate> gates;
     gates_of(circ, gates);
-    Plan plan;
-    if (!build_plan(circ->num_q, p, gates, plan)) return -1;
-    long w = 0;
-    int locals = 0;
-    for (const Step &st : plan.steps) {
-        if (!st.exchange) { locals++; continue; }
-        const int k = (int)st.J.size();
-        if (steps_out && w + 1 + 2 * k <= cap) {
-            steps_out[w] = k;
-            for (int i = 0; i < k; i++) { steps_out[w + 1 + i] = st.J[i]; steps_out[w + 1 + k + i] = st.Lsel[i]; }
-        }
-        w += 1 + 2 * k;
+    qsim_shard_plan *sp = new qsim_shard_plan();
+    sp->P = num_shards;
+    if (!build_plan(circ->num_q, p, gates, sp->plan)) {
+        delete sp;
+        return cfail(QSIM_ERR_ARG, "planner made no progress");
     }
-    if (final_pos)
-        for (int q = 0; q < circ->num_q; q++) final_pos[q] = plan.final_pos[q];
-    if (n_local_steps) *n_local_steps = locals;
-    return w;
+    *out = sp;
+    return QSIM_OK;
+}
+
+extern "C" void qsim_shard_plan_free(qsim_shard_plan *p) { delete p; }
+extern "C" int qsim_shard_plan_num_steps(const qsim_shard_plan *p) { return p ? (int)p->plan.steps.size() : -1; }
+
+extern "C" int qsim_shard_plan_step(const qsim_shard_plan *p, int step, int *kind, int *k, int *shard_bits, int *local_bits) {
+    if (!p || step < 0 || step >= (int)p->plan.steps.size()) return QSIM_ERR_ARG;
+    const Step &st = p->plan.steps[step];
+    if (kind) *kind = st.exchange ? 1 : 0;
+    if (k) *k = (int)st.J.size();
+    for (size_t i = 0; i < st.J.size(); i++) {
+        if (shard_bits) shard_bits[i] = st.J[i];
+        if (local_bits) local_bits[i] = st.Lsel[i];
+    }
+    return QSIM_OK;
+}
+
+extern "C" int qsim_shard_plan_final_pos(const qsim_shard_plan *p, int *pos) {
+    if (!p || !pos) return QSIM_ERR_ARG;
+    for (size_t q = 0; q < p->plan.final_pos.size(); q++) pos[q] = p->plan.final_pos[q];
+    return QSIM_OK;
+}
+
+extern "C" int qsim_shard_plan_local_ops(const qsim_shard_plan *p, int step, int shard, qsim_local_op_cb cb, void *user) {
+    if (!p || !cb || step < 0 || step >= (int)p->plan.steps.size() || shard < 0 || shard >= p->P) return QSIM_ERR_ARG;
+    const Step &st = p->plan.steps[step];
+    if (st.exchange) return QSIM_ERR_ARG;
+    for (const LocalOp &o : st.per_shard[shard]) {
+        const double m[8] = {o.m[0].real(), o.m[0].imag(), o.m[1].real(), o.m[1].imag(),
+                             o.m[2].real(), o.m[2].imag(), o.m[3].real(), o.m[3].imag()};
+        cb(user, o.kind, o.a, o.b, m);
+    }
+    return QSIM_OK;
+}
+
+extern "C" int qsim_shard_plan_apply_local(const qsim_shard_plan *p, int step, int shard, qsim_state *s) {
+    if (!p || !s || step < 0 || step >= (int)p->plan.steps.size() || shard < 0 || shard >= p->P) return cfail(QSIM_ERR_ARG, "bad argument");
+    const Step &st = p->plan.steps[step];
+    if (st.exchange) return cfail(QSIM_ERR_ARG, "step %d is an exchange", step);
+    for (const LocalOp &o : st.per_shard[shard]) {
+        int rc;
+        if (o.kind == 2) rc = qsim_apply_cx(s, o.a, o.b);
+        else if (o.kind == 1) {
+            const double U[8] = {o.m[0].real(), o.m[0].imag(), o.m[1].real(), o.m[1].imag(),
+                                 o.m[2].real(), o.m[2].imag(), o.m[3].real(), o.m[3].imag()};
+            rc = qsim_apply_1q(s, U, o.a);
+        } else rc = qsim_scale(s, o.m[0].real(), o.m[0].imag());
+        if (rc) return cfail(rc, "%s", qsim_last_error());
+    }
+    return QSIM_OK;
 }

@@ -16,8 +16,9 @@ gate never forces data to move by itself:
     relabelling idea (quantum_simulator_4x4_permute.cu:377-434) with the objective inverted: hot -> local.
   * the initial |0...0> is symmetric under qubit permutations, so the first placement is free.
 
-The planner is plain Python and identical on every rank (only the emitted per-rank scalars / X gates
-differ), so ranks never need to agree on anything at run time.  `VirtualCluster` drives P shards inside
+The planner is the C++ one inside libqsim (csrc/dist.cpp, shared with the C host's qsim_cluster) and is deterministic:
+every rank builds the same plan (only its own per-rank scalars / X gates differ), so ranks never need to agree on
+anything at run time.  `VirtualCluster` drives P shards inside
 one process (exchange = plain copies) so the whole path is testable on one GPU or, with a CPU shard
 backend supplied by the tests, on no GPU at all.
 """
@@ -56,138 +57,51 @@ def normalize_gates(gates: Sequence[Sequence], gate_matrix: Callable[[str], np.n
 
 
 class ShardPlan:
-    """Steps for one rank: ('local', [ops]) and ('exchange', rank_bits, local_positions).
+    """Steps for one rank, produced by the C++ planner in libqsim (csrc/dist.cpp, the same one the C host's
+    qsim_cluster uses): ('local', [ops]) and ('exchange', rank_bits, local_positions).
 
-    ops: ('u1', local_pos, U) | ('cx', cpos, tpos) | ('scale', z).  Every rank sees the same sequence of
-    step kinds and the same exchanges."""
+    ops: ('u1', local_pos, U) | ('cx', cpos, tpos) | ('scale', z).  Every rank sees the same sequence of step kinds and
+    the same exchanges; only the per-rank scalars / conditional X gates differ."""
 
-    def __init__(self, n: int, p: int, gates: List[Tuple], rank: int, lookahead_free_start: bool = True):
-        assert 0 <= p <= n - 2 or p == 0, "need at least two local qubits"
+    def __init__(self, n: int, p: int, gates: List[Tuple], rank: int):
+        from .simulator import Circuit, ShardPlanHandle
         self.n, self.p, self.m, self.rank = n, p, n - p, rank
+        circ = Circuit.empty(n)
+        for g in gates:
+            if g[0] == "cx":
+                circ.append_cx(g[1], g[2])
+            else:
+                circ.append_1q(g[2], g[1])
+        self.handle = ShardPlanHandle(circ, 1 << p)
         self.steps: List[Tuple] = []
         self.exchanges = 0
-        self.exchanged_fraction = 0.0  # sum over exchanges of the shard fraction sent
-        pos = list(range(n))  # logical -> physical
-        remaining = list(gates)
-        first = True
-        while remaining:
-            if self.p and first and lookahead_free_start:
-                # |0...0> is permutation-symmetric: choose the first global set for free
-                new_glob = self._choose_globals(remaining, pos)
-                self._relabel_free(pos, new_glob)
-            first = False
-            run, deferred = self._split(remaining, pos)
-            if run:
-                self.steps.append(("local", self._emit(run, pos)))
-            if deferred:
-                new_glob = self._choose_globals(deferred, pos)
-                J, Lsel = self._exchange(pos, new_glob)
-                if not J:
-                    raise RuntimeError("planner made no progress")
-                self.steps.append(("exchange", tuple(J), tuple(Lsel)))
+        self.exchanged_fraction = 0.0
+        for i in range(self.handle.num_steps):
+            st = self.handle.step(i)
+            if st[0] == "local":
+                self.steps.append(("local", self.handle.local_ops(i, rank)))
+            else:
+                self.steps.append(st)
                 self.exchanges += 1
-                self.exchanged_fraction += 1.0 - 2.0 ** (-len(J))
-            remaining = deferred
-        self.final_pos = pos
+                self.exchanged_fraction += 1.0 - 2.0 ** (-len(st[1]))
+        self.final_pos = self.handle.final_pos()
 
-    # -- which gates can run under the current placement
-    def _needs_local(self, g) -> Tuple[int, ...]:
-        """Logical qubits this gate needs in local positions."""
-        if g[0] == "cx":
-            return (g[2],) if g[1] != g[2] else ()
-        return () if _is_diag(g[2]) else (g[1],)
-
-    def _split(self, gates, pos):
-        m = self.m
-        run, deferred, blocked = [], [], set()
-        for g in gates:
-            qs = {g[1], g[2]} if g[0] == "cx" else {g[1]}
-            if qs & blocked:
-                blocked |= qs
-                deferred.append(g)
-                continue
-            if all(pos[q] < m for q in self._needs_local(g)):
-                run.append(g)
-            else:
-                blocked |= qs
-                deferred.append(g)
-        return run, deferred
-
-    def _emit(self, run, pos):
-        m, ops = self.m, []
-        for g in run:
-            if g[0] == "cx":
-                c, t = g[1], g[2]
-                if c == t:
-                    continue
-                if pos[c] < m:
-                    ops.append(("cx", pos[c], pos[t]))
-                elif (self.rank >> (pos[c] - m)) & 1:
-                    ops.append(("u1", pos[t], _X))
-            else:
-                q, U = g[1], g[2]
-                if pos[q] < m:
-                    ops.append(("u1", pos[q], U))
-                else:
-                    b = (self.rank >> (pos[q] - m)) & 1
-                    z = complex(U[b, b])
-                    if z != 1.0:
-                        ops.append(("scale", z))
-        return ops
-
-    # -- placement
-    def _choose_globals(self, gates, pos) -> List[int]:
-        """The p logical qubits whose next use that needs locality is furthest away."""
-        nxt = [INF] * self.n
-        found = 0
-        for i, g in enumerate(gates):
-            for q in self._needs_local(g):
-                if nxt[q] == INF:
-                    nxt[q] = i
-                    found += 1
-            if found == self.n:
-                break
-        # prefer: far next use; then already-global (nothing to move); then a high position (long pack runs)
-        order = sorted(range(self.n), key=lambda q: (nxt[q], pos[q] >= self.m, pos[q]), reverse=True)
-        return order[: self.p]
-
-    def _relabel_free(self, pos, new_glob):
-        """Initial placement: permute the map without moving data."""
-        m = self.m
-        cur_glob = [q for q in range(self.n) if pos[q] >= m]
-        outgoing = [q for q in new_glob if pos[q] < m]
-        incoming = [q for q in cur_glob if q not in new_glob]
-        for a, b in zip(outgoing, incoming):
-            pos[a], pos[b] = pos[b], pos[a]
-
-    def _exchange(self, pos, new_glob):
-        """Updates pos for swapping the outgoing locals with the incoming globals; returns (rank bit ids,
-        local positions), both ascending and paired in that order."""
-        m = self.m
-        cur_glob = [q for q in range(self.n) if pos[q] >= m]
-        outgoing = sorted((q for q in new_glob if pos[q] < m), key=lambda q: pos[q])
-        incoming = sorted((q for q in cur_glob if q not in new_glob), key=lambda q: pos[q])
-        k = len(outgoing)
-        assert k == len(incoming)
-        if k == 0:
-            return [], []
-        Lsel = [pos[q] for q in outgoing]
-        J = [pos[q] - m for q in incoming]
-        sel = set(Lsel)
-        # remaining locals compact downwards in order; incoming globals land in the top k local positions
-        newpos = list(pos)
-        for q in range(self.n):
-            if pos[q] < m and pos[q] not in sel:
-                newpos[q] = pos[q] - sum(1 for s in Lsel if s < pos[q])
-        for i, q in enumerate(incoming):
-            newpos[q] = m - k + i
-        for i, q in enumerate(outgoing):
-            newpos[q] = m + J[i]
-        pos[:] = newpos
-        return J, Lsel
+    def apply_local(self, step: int, sim) -> None:
+        """Queues this rank's ops of a local step on a Simulator, natively."""
+        self.handle.apply_local(step, self.rank, sim)
 
 
 _X = np.array([[0, 1], [1, 0]], dtype=np.complex128)
+
+
+def _bind(shard, plan: "ShardPlan") -> None:
+    """HipShard takes the plan itself; test backends (CPU shards) take the per-step op lists."""
+    if hasattr(shard, "bind_plan"):
+        shard.bind_plan(plan)
+    else:
+        for i, st in enumerate(plan.steps):
+            if st[0] == "local":
+                shard.compile(i, st[1])
 
 
 def peers_of(rank: int, J: Sequence[int]) -> Tuple[int, List[int]]:
@@ -214,19 +128,11 @@ class HipShard:
         self.state = torch.empty((1 << m, 2), dtype=torch.float64, device=self.dev)
         self.scratch = torch.empty((1 << m, 2), dtype=torch.float64, device=self.dev)
         self.sim = Simulator(m, device, fuse=fuse, profile=profile, external_ptr=self.state.data_ptr(), **opts)
-        self._Circuit = Circuit
-        self._compiled: Dict[int, object] = {}
+        self._plan = None
 
-    def compile(self, key: int, ops):
-        c = self._Circuit.empty(self.m)
-        for op in ops:
-            if op[0] == "cx":
-                c.append_cx(op[1], op[2])
-            elif op[0] == "u1":
-                c.append_1q(op[2], op[1])
-            else:
-                c.append_1q(np.diag([op[1], op[1]]), 0)  # per-rank scalar, folds into the next fused block
-        self._compiled[key] = c
+    def bind_plan(self, plan: "ShardPlan"):
+        """Local steps are queued straight from the C++ plan (qsim_shard_plan_apply_local): no Python per gate."""
+        self._plan = plan
 
     # The buffers belong to torch's HIP runtime, libqsim runs on the system one (see _lib.load): device
     # addresses are shared process-wide, so kernels work on them directly, but host<->device copies and
@@ -235,7 +141,7 @@ class HipShard:
         self.sim.reset(holds_index0)
 
     def apply_local(self, key: int):
-        self.sim.run(self._compiled[key])
+        self._plan.apply_local(key, self.sim)
         self.sim.flush()
 
     def pack(self, Lsel):
@@ -282,9 +188,7 @@ class ShardedSimulator:
         self.n, self.p, self.m = n, p, n - p
         self.plan = ShardPlan(n, p, normalize_gates(gates, gate_matrix), self.rank)
         self.shard = (shard_factory or HipShard)(self.m, device, fuse=fuse, profile=profile, **opts)
-        for i, st in enumerate(self.plan.steps):
-            if st[0] == "local":
-                self.shard.compile(i, st[1])
+        _bind(self.shard, self.plan)
         self.exchange_seconds = 0.0
         self.exchange_bytes = 0
         self._warm_up_links()
@@ -423,9 +327,7 @@ class VirtualCluster:
         factory = shard_factory or HipShard
         self.shards = [factory(self.m, device, **opts) for _ in range(world)]
         for r in range(world):
-            for i, st in enumerate(self.plans[r].steps):
-                if st[0] == "local":
-                    self.shards[r].compile(i, st[1])
+            _bind(self.shards[r], self.plans[r])
 
     def run(self):
         for r, sh in enumerate(self.shards):

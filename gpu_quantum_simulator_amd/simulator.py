@@ -327,22 +327,63 @@ class Cluster:
             pass
 
 
-def plan_shards(circuit: Circuit, num_shards: int):
-    """The C++ planner's exchanges [(shard_bits, local_positions)], final logical->physical map and local-step count."""
-    lib = _lib.load()
-    cap = 4096
-    buf = (c_int * cap)()
-    pos = (c_int * circuit.num_qubits)()
-    locals_ = c_int()
-    w = lib.qsim_plan_shards(circuit._h, num_shards, buf, cap, pos, byref(locals_))
-    if w < 0 or w > cap:
-        raise RuntimeError("qsim_plan_shards failed")
-    out, i = [], 0
-    while i < w:
-        k = buf[i]
-        out.append((tuple(buf[i + 1:i + 1 + k]), tuple(buf[i + 1 + k:i + 1 + 2 * k])))
-        i += 1 + 2 * k
-    return out, list(pos), locals_.value
+class ShardPlanHandle:
+    """qsim_shard_plan: the C++ planner's output for one circuit and shard count (host only)."""
+
+    def __init__(self, circuit: Circuit, num_shards: int):
+        self._h = c_void_p()
+        lib = _lib.load()
+        rc = lib.qsim_shard_plan_create(byref(self._h), circuit._h, num_shards)
+        if rc:
+            raise _lib.QsimError(rc, (lib.qsim_cluster_error() or b"").decode())
+        self.num_shards = num_shards
+        self.num_qubits = circuit.num_qubits
+        self.num_steps = lib.qsim_shard_plan_num_steps(self._h)
+
+    def step(self, i: int):
+        """("local",) or ("exchange", shard_bits, local_positions)."""
+        kind, k = c_int(), c_int()
+        J, L = (c_int * 16)(), (c_int * 16)()
+        check(_lib.load().qsim_shard_plan_step(self._h, i, byref(kind), byref(k), J, L))
+        if kind.value == 0:
+            return ("local",)
+        return ("exchange", tuple(J[: k.value]), tuple(L[: k.value]))
+
+    def local_ops(self, i: int, shard: int) -> list:
+        """[("u1", pos, U) | ("cx", a, b) | ("scale", z)] for one shard."""
+        out = []
+
+        def cb(_u, kind, a, b, m):
+            if kind == 1:
+                out.append(("u1", a, np.ctypeslib.as_array(m, shape=(8,)).copy().view(np.complex128).reshape(2, 2)))
+            elif kind == 2:
+                out.append(("cx", a, b))
+            else:
+                out.append(("scale", complex(m[0], m[1])))
+
+        check(_lib.load().qsim_shard_plan_local_ops(self._h, i, shard, _lib.LOCAL_OP_CB(cb), None))
+        return out
+
+    def apply_local(self, i: int, shard: int, sim: "Simulator") -> None:
+        rc = _lib.load().qsim_shard_plan_apply_local(self._h, i, shard, sim._h)
+        if rc:
+            raise _lib.QsimError(rc, (_lib.load().qsim_cluster_error() or b"").decode())
+
+    def final_pos(self) -> list:
+        pos = (c_int * self.num_qubits)()
+        check(_lib.load().qsim_shard_plan_final_pos(self._h, pos))
+        return list(pos)
+
+    def close(self) -> None:
+        if self._h:
+            _lib.load().qsim_shard_plan_free(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def run_qasm(path: str, device: int = 0, **sim_options) -> np.ndarray:

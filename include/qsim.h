@@ -168,10 +168,20 @@ int qsim_cluster_read(qsim_cluster *c, uint64_t logical_first, uint64_t count, d
 int qsim_cluster_norm2(qsim_cluster *c, double *out);
 int qsim_cluster_exchange_stats(const qsim_cluster *c, uint64_t *exchanges, double *bytes_per_shard);
 const char *qsim_cluster_error(void);
-/* Host-only planner output: per exchange k, then k shard-id bits, then k local bit positions (ascending, paired).
- * Returns the number of ints written (or needed), -1 on error. */
-long qsim_plan_shards(const qsim_circuit *circuit, int num_shards, int *steps_out, long cap, int *final_pos,
-                      int *n_local_steps);
+/* The plan as an object (host only).  This is what the one-process-per-GPU driver executes: every rank builds the same
+ * plan, applies its own local steps with qsim_shard_plan_apply_local on its shard state and performs the exchanges
+ * (qsim_pack_bits + send/recv of the blocks) itself.  step kinds: 0 local, 1 exchange (k shard-id bits and k local bit
+ * positions, ascending and paired).  local ops: 1 = 2x2 on local qubit a (m = 8 doubles), 2 = cx a -> b,
+ * 3 = multiply the shard by the scalar m[0..1]. */
+typedef struct qsim_shard_plan qsim_shard_plan;
+typedef void (*qsim_local_op_cb)(void *user, int kind, int a, int b, const double *m);
+int qsim_shard_plan_create(qsim_shard_plan **out, const qsim_circuit *circuit, int num_shards);
+void qsim_shard_plan_free(qsim_shard_plan *p);
+int qsim_shard_plan_num_steps(const qsim_shard_plan *p);
+int qsim_shard_plan_step(const qsim_shard_plan *p, int step, int *kind, int *k, int *shard_bits, int *local_bits);
+int qsim_shard_plan_final_pos(const qsim_shard_plan *p, int *pos /* num_q entries: logical -> physical */);
+int qsim_shard_plan_local_ops(const qsim_shard_plan *p, int step, int shard, qsim_local_op_cb cb, void *user);
+int qsim_shard_plan_apply_local(const qsim_shard_plan *p, int step, int shard, qsim_state *s);
 
 int qsim_get_stats(qsim_state *s, qsim_stats *out); /* waits for outstanding profile events */
 int qsim_reset_stats(qsim_state *s);

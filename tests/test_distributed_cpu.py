@@ -16,6 +16,7 @@ from gpu_quantum_simulator_amd import circuits, gate_matrix
 from gpu_quantum_simulator_amd.distributed import (ShardPlan, ShardedSimulator, VirtualCluster, normalize_gates,
                                                    logical_from_physical, peers_of, physical_index)
 from cpu_shard import CpuShard
+from py_shard_plan import PyShardPlan
 
 TOL = 1e-12
 
@@ -58,11 +59,11 @@ def test_communication_free_gates_stay_local():
     n, p = 8, 2
     gates = [("h", q) for q in range(6)] + [("t", 7), ("rz", 0.3, 6), ("cx", 7, 2), ("cx", 6, 0), ("z", 7), ("s", 6)]
     norm = normalize_gates(gates, gate_matrix)
-    pl = ShardPlan(n, p, norm, rank=3, lookahead_free_start=False)
+    pl = PyShardPlan(n, p, norm, rank=3, lookahead_free_start=False)
     assert pl.exchanges == 0 and [s[0] for s in pl.steps] == ["local"]
     kinds = [op[0] for op in pl.steps[0][1]]
     assert kinds.count("scale") == 4 and kinds.count("u1") == 6 + 2  # rank 3 has both control bits set
-    pl0 = ShardPlan(n, p, norm, rank=0, lookahead_free_start=False)
+    pl0 = PyShardPlan(n, p, norm, rank=0, lookahead_free_start=False)
     assert [op[0] for op in pl0.steps[0][1]].count("u1") == 6  # controls clear, all scalars are 1
 
 
@@ -70,8 +71,8 @@ def test_free_initial_placement_avoids_first_exchange():
     n, p = 8, 2
     gates = [("h", 7), ("h", 6), ("cx", 7, 6)] + [("t", 0), ("z", 1)]
     norm = normalize_gates(gates, gate_matrix)
-    assert ShardPlan(n, p, norm, 0).exchanges == 0
-    assert ShardPlan(n, p, norm, 0, lookahead_free_start=False).exchanges == 1
+    assert ShardPlan(n, p, norm, 0).exchanges == 0 and PyShardPlan(n, p, norm, 0).exchanges == 0
+    assert PyShardPlan(n, p, norm, 0, lookahead_free_start=False).exchanges == 1
 
 
 def test_peers_and_index_helpers():
@@ -131,14 +132,27 @@ def test_gloo_ranks_equal_oracle(oracle, tmp_path, world):
 @pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("n,depth,seed,vocab", [(8, 300, 11, "all"), (12, 600, 12, "all"), (16, 800, 13, "clifford_t"),
                                                 (30, 1000, 20240147, "all")])
-def test_cpp_planner_equals_python_planner(world, n, depth, seed, vocab):
-    """libqsim's planner (csrc/dist.cpp, used by the C host) and distributed.ShardPlan (used by the torch.distributed
-    driver) must produce the same exchanges and the same final qubit map."""
-    from gpu_quantum_simulator_amd import Circuit, plan_shards
-    gates = circuits.random_gates(n, depth, seed, vocab)
+def test_cpp_planner_equals_python_restatement(world, n, depth, seed, vocab):
+    """libqsim's planner (csrc/dist.cpp: the product path of both the C host and distributed.py) against the
+    independent pure-Python restatement in tests/py_shard_plan.py: same exchanges, same final qubit map, and the same
+    per-rank local ops on every rank."""
+    gates = normalize_gates(circuits.random_gates(n, depth, seed, vocab), gate_matrix)
     p = world.bit_length() - 1
-    py = ShardPlan(n, p, normalize_gates(gates, gate_matrix), rank=0)
-    exchanges, final_pos, n_local = plan_shards(Circuit.from_gates(n, gates), world)
-    assert exchanges == [(s[1], s[2]) for s in py.steps if s[0] == "exchange"]
-    assert final_pos == py.final_pos
-    assert n_local == sum(1 for s in py.steps if s[0] == "local")
+    for rank in sorted({0, 1, world - 1}):
+        py = PyShardPlan(n, p, gates, rank=rank)
+        cc = ShardPlan(n, p, gates, rank=rank)
+        assert [s[0] for s in cc.steps] == [s[0] for s in py.steps]
+        assert cc.final_pos == py.final_pos and cc.exchanges == py.exchanges
+        for a, b in zip(cc.steps, py.steps):
+            if a[0] == "exchange":
+                assert a == b
+            else:
+                assert len(a[1]) == len(b[1])
+                for x, y in zip(a[1], b[1]):
+                    assert x[0] == y[0]
+                    if x[0] == "cx":
+                        assert x[1:] == y[1:]
+                    elif x[0] == "u1":
+                        assert x[1] == y[1] and np.array_equal(x[2], y[2])
+                    else:
+                        assert x[1] == y[1]

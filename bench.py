@@ -52,13 +52,16 @@ def parse_args():
                     help="strong: the same n on every N (default, the metric is quoted at n=30); weak: n = qubits + log2(N)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="with --gpus 1: still go through torch.distributed + ShardedSimulator (rehearsal of the N>1 code path)")
+    ap.add_argument("--precision", type=int, default=64, choices=[64, 32],
+                    help="64 = the headline / parity configuration; 32 = fp32 state like the reference's CUDA variants "
+                         "(an extra measurement, single GPU only, reported with dtype f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
-KERNEL_SYMBOL = {"tile": "qsim::k_tile<12, 512>", "gate1": "qsim::k_gate1_hi<4, false>",
-                 "gate1_lo": "qsim::k_gate1_lo<4, false>", "gate2": "qsim::k_gate2_hh<2, false>"}
+KERNEL_SYMBOL = {"tile": "k_tile<12, 512>", "gate1": "k_gate1_hi<4, false>",
+                 "gate1_lo": "k_gate1_lo<4, false>", "gate2": "k_gate2_hh<2, false>"}  # inside namespace qsim::f64
 
 
 def pmc_traffic(kernel_class, is_default_workload):
@@ -73,8 +76,11 @@ def pmc_traffic(kernel_class, is_default_workload):
         return None
     with open(files[-1]) as f:
         summary = json.load(f)
-    entry = summary.get("kernels", {}).get(KERNEL_SYMBOL.get(kernel_class, ""), None)
-    return entry["hbm_traffic_bytes_per_launch"] if entry else None
+    want = KERNEL_SYMBOL.get(kernel_class)
+    for name, entry in summary.get("kernels", {}).items():
+        if want and name.endswith("::" + want) and "f32" not in name:
+            return entry["hbm_traffic_bytes_per_launch"]
+    return None
 
 
 def cpu_baseline(n, gates, budget_s):
@@ -148,6 +154,8 @@ def main():
                               ("tile_max_ops", args.tile_max_ops), ("grid_cap", args.grid_cap)) if v is not None}
 
     dist = None
+    if args.precision == 32 and (world > 1 or args.force_sharded):
+        sys.exit("--precision 32 is single-GPU only (shards and clusters are fp64)")
     if world > 1 or args.force_sharded:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -160,7 +168,7 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
         circuit = Circuit.from_gates(n, gates)
-        sim = Simulator(n, local_rank, fuse=fuse, profile=True, **opts)
+        sim = Simulator(n, local_rank, fuse=fuse, profile=True, precision=args.precision, **opts)
 
         def run_step():
             sim.reset()
@@ -220,7 +228,7 @@ def main():
             achieved = kernels[dom]["bytes"] / (kernels[dom]["ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS,
-                    "traffic": pmc_traffic(dom, args.probe is None and n == 30 and args.depth == 1000 and fuse == 3
+                    "traffic": pmc_traffic(dom, args.precision == 64 and args.probe is None and n == 30 and args.depth == 1000 and fuse == 3
                                            and args.gpus == 1 and not opts and args.vocabulary == "all"),
                     "launches": kernels[dom]["launches"],
                     "avg_launch_ms": kernels[dom]["ms"] / kernels[dom]["launches"],
@@ -229,9 +237,9 @@ def main():
         out = {
             "metric": "gate-applies/sec", "value": value, "unit": "gate-applies/s", "n_gpus": args.gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
             "config": {"workload": workload, "qubits": n, "gate_statements": args.depth, "fuse": fuse,
-                       "state_bytes": 16 * (1 << n), "parallelism": f"shard{args.gpus}", **opts},
+                       "state_bytes": (16 if args.precision == 64 else 8) * (1 << n), "parallelism": f"shard{args.gpus}", **opts},
             "hbm_gbps_all_kernels": stats["algorithmic_bytes"] / (total_kernel_ms * 1e-3) / 1e9 if total_kernel_ms else None,
             "launches_per_step": stats["launches"] / args.steps,
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in stats["kernels"].items() if v["launches"]},

@@ -40,6 +40,8 @@ SIGNATURES = {
     "qsim_device_init": (c_int, [c_int]),
     "qsim_last_error": (c_char_p, []),
     "qsim_create": (c_int, [POINTER(c_void_p), c_int, c_int]),
+    "qsim_create_f32": (c_int, [POINTER(c_void_p), c_int, c_int]),
+    "qsim_precision_bits": (c_int, [c_void_p]),
     "qsim_create_external": (c_int, [POINTER(c_void_p), c_int, c_int, c_void_p]),
     "qsim_destroy": (None, [c_void_p]),
     "qsim_reset": (c_int, [c_void_p]),

@@ -71,8 +71,10 @@ struct LaunchRec { int kclass, n_ops; uint64_t high_mask; double ms; };
 struct qsim_state {
     int n = 0, device = 0;
     hipStream_t stream = nullptr;
-    double2 *amps = nullptr;
+    void *amps = nullptr; // 2^n amplitudes: (re, im) pairs of double (16 B) or, with f32, of float (8 B)
+    bool f32 = false;
     bool owns = false;
+    size_t amp_bytes() const { return f32 ? 8 : 16; }
     // options
     int fuse = 3, profile = 0, tile_bits = 12, tile_low_bits = 3, tile_max_ops = 32, grid_cap = 0, tile_threads = 0, tile_pad_from = 10;
     long max_pending = 1L << 16;
@@ -93,7 +95,7 @@ struct qsim_state {
 
 static constexpr size_t kOpsCap = 2048; // a pass holds <= tile_max_ops blocks; the ring wraps with a stream sync
 
-static int make_state(qsim_state **out, int num_q, int device, void *ext) {
+static int make_state(qsim_state **out, int num_q, int device, void *ext, bool f32 = false) {
     if (!out) return fail(QSIM_ERR_ARG, "qsim_create: out is NULL");
     *out = nullptr;
     if (num_q < 0 || num_q > 40) return fail(QSIM_ERR_ARG, "qsim_create: %d qubits unsupported", num_q);
@@ -105,11 +107,13 @@ static int make_state(qsim_state **out, int num_q, int device, void *ext) {
     qsim_state *s = new qsim_state();
     s->n = num_q;
     s->device = device;
-    const size_t bytes = (size_t)16 << num_q;
+    s->f32 = f32;
+    if (f32) s->tile_bits = 13; // same 64 KiB of LDS per tile as the fp64 default, one more qubit per pass
+    const size_t bytes = s->amp_bytes() << num_q;
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e == hipSuccess) {
-        if (ext) s->amps = (double2 *)ext;
-        else { e = hipMalloc((void **)&s->amps, bytes); s->owns = (e == hipSuccess); }
+        if (ext) s->amps = ext;
+        else { e = hipMalloc(&s->amps, bytes); s->owns = (e == hipSuccess); }
     }
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_ops, kOpsCap * sizeof(TileOp));
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_ops, kOpsCap * sizeof(TileOp), hipHostMallocDefault);
@@ -126,6 +130,8 @@ static int make_state(qsim_state **out, int num_q, int device, void *ext) {
 }
 
 extern "C" int qsim_create(qsim_state **out, int num_q, int device) { return make_state(out, num_q, device, nullptr); }
+extern "C" int qsim_create_f32(qsim_state **out, int num_q, int device) { return make_state(out, num_q, device, nullptr, true); }
+extern "C" int qsim_precision_bits(const qsim_state *s) { return s ? (s->f32 ? 32 : 64) : -1; }
 extern "C" int qsim_create_external(qsim_state **out, int num_q, int device, void *device_amps) {
     if (!device_amps) return fail(QSIM_ERR_ARG, "qsim_create_external: device_amps is NULL");
     return make_state(out, num_q, device, device_amps);
@@ -146,7 +152,7 @@ extern "C" void qsim_destroy(qsim_state *s) {
 }
 
 extern "C" int qsim_num_qubits(const qsim_state *s) { return s ? s->n : -1; }
-extern "C" void *qsim_device_ptr(qsim_state *s) { return s ? (void *)s->amps : nullptr; }
+extern "C" void *qsim_device_ptr(qsim_state *s) { return s ? s->amps : nullptr; }
 extern "C" void *qsim_stream(qsim_state *s) { return s ? (void *)s->stream : nullptr; }
 
 extern "C" int qsim_set_option(qsim_state *s, int option, long value) {
@@ -162,7 +168,7 @@ extern "C" int qsim_set_option(qsim_state *s, int option, long value) {
         break;
     case QSIM_OPT_PROFILE: s->profile = value != 0; break;
     case QSIM_OPT_TILE_BITS:
-        if (value < 8 || value > 13) return fail(QSIM_ERR_ARG, "tile_bits %ld not in 8..13", value);
+        if (value < 8 || value > (s->f32 ? 14 : 13)) return fail(QSIM_ERR_ARG, "tile_bits %ld not in 8..%d", value, s->f32 ? 14 : 13);
         s->tile_bits = (int)value;
         break;
     case QSIM_OPT_TILE_LOW_BITS:
@@ -273,9 +279,9 @@ static int materialize_zero_ket(qsim_state *s) {
     LaunchCfg cfg{s->stream, s->grid_cap};
     {
         LaunchScope scope(s, QSIM_K_INIT);
-        HIP_TRY(launch_init(cfg, s->amps, s->n, s->zero_ket_amp));
+        HIP_TRY(launch_init(cfg, s->amps, s->f32, s->n, s->zero_ket_amp));
     }
-    account(s, QSIM_K_INIT, 16.0 * (double)(1ULL << s->n));
+    account(s, QSIM_K_INIT, (double)s->amp_bytes() * (double)(1ULL << s->n));
     return QSIM_OK;
 }
 
@@ -354,7 +360,7 @@ static inline int local_bit(const TileGeom &g, int q) {
 
 // FusedOp -> device TileOp.  Returns false when a qubit is outside the tile or the block cannot be expressed
 // (a 3-qubit block with more than 4 entries per row; merge_sparse never produces one).
-static bool to_tile_op(const TileGeom &g, const FusedOp &op, TileOp &t) {
+static bool to_tile_op(const TileGeom &g, const FusedOp &op, TileOp &t, int amp_shift = 4) {
     memset(&t, 0, sizeof t);
     const int k = op.nq(), D = op.dim();
     const int qs[3] = {op.q_hi, op.q_lo, op.q_lo2}; // most significant first
@@ -402,17 +408,17 @@ static bool to_tile_op(const TileGeom &g, const FusedOp &op, TileOp &t) {
         return o ^ (((o >> 4) & 1u) * 15u);
     };
     for (int r = 0; r < D; r++) {
-        t.rowoff[r] = slot_off(r) * 16u;
+        t.rowoff[r] = slot_off(r) << amp_shift;
         int j = 0;
         for (int c = 0; c < D; c++)
             if (nz(r, c)) {
                 const int e = r * T + j++;
-                t.off[e] = slot_off(c) * 16u;
+                t.off[e] = slot_off(c) << amp_shift;
                 t.re[e] = op.m[D * r + c].real();
                 t.im[e] = op.m[D * r + c].imag();
             }
         if (j == 1 && nz(r, r) && is1(op.m[D * r + r])) t.meta |= 1 << r; // identity row: no traffic at all
-        for (; j < T; j++) t.off[r * T + j] = slot_off(r) * 16u; // pad: zero coefficient on the row's own slot
+        for (; j < T; j++) t.off[r * T + j] = slot_off(r) << amp_shift; // pad: zero coefficient on the row's own slot
     }
     return true;
 }
@@ -433,28 +439,28 @@ static int launch_pass(qsim_state *s, const Pass &p) {
         M2 u;
         to_m2(op, u);
         LaunchScope scope(s, p.kclass);
-        e = launch_gate1(cfg, s->amps, s->n, op.q_hi, u);
+        e = launch_gate1(cfg, s->amps, s->f32, s->n, op.q_hi, u);
         break;
     }
     case QSIM_K_PHASE: {
         LaunchScope scope(s, p.kclass);
         if (p.diag_full)
-            e = launch_diag1_full(cfg, s->amps, s->n, op.q_hi, op.m[0].real(), op.m[0].imag(), op.m[3].real(),
+            e = launch_diag1_full(cfg, s->amps, s->f32, s->n, op.q_hi, op.m[0].real(), op.m[0].imag(), op.m[3].real(),
                                   op.m[3].imag());
         else
-            e = launch_phase(cfg, s->amps, s->n, op.q_hi, op.m[3].real(), op.m[3].imag());
+            e = launch_phase(cfg, s->amps, s->f32, s->n, op.q_hi, op.m[3].real(), op.m[3].imag());
         break;
     }
     case QSIM_K_CX: {
         LaunchScope scope(s, p.kclass);
-        e = launch_cx(cfg, s->amps, s->n, op.q_hi, op.q_lo);
+        e = launch_cx(cfg, s->amps, s->f32, s->n, op.q_hi, op.q_lo);
         break;
     }
     case QSIM_K_GATE2: {
         M4 u;
         to_m4(op, u);
         LaunchScope scope(s, p.kclass);
-        e = launch_gate2(cfg, s->amps, s->n, op.q_hi, op.q_lo, u);
+        e = launch_gate2(cfg, s->amps, s->f32, s->n, op.q_hi, op.q_lo, u);
         break;
     }
     case QSIM_K_TILE: {
@@ -466,7 +472,14 @@ static int launch_pass(qsim_state *s, const Pass &p) {
         }
         TileOp *h = s->h_ops + s->ops_used;
         for (size_t k = 0; k < need; k++)
-            if (!to_tile_op(p.geom, p.ops[k], h[k])) return fail(QSIM_ERR_ARG, "internal: block does not fit its tile pass");
+            if (!to_tile_op(p.geom, p.ops[k], h[k], s->f32 ? 3 : 4)) return fail(QSIM_ERR_ARG, "internal: block does not fit its tile pass");
+        if (s->f32) // the fp32 kernels read float coefficients from the front of re[] / im[] (rounded once, here)
+            for (size_t k = 0; k < need; k++) {
+                float fr[32], fi[32];
+                for (int e = 0; e < 32; e++) { fr[e] = (float)h[k].re[e]; fi[e] = (float)h[k].im[e]; }
+                memcpy(h[k].re, fr, sizeof fr);
+                memcpy(h[k].im, fi, sizeof fi);
+            }
         TileOp *d = s->d_ops + s->ops_used;
         HIP_TRY(hipMemcpyAsync(d, h, need * sizeof(TileOp), hipMemcpyHostToDevice, s->stream));
         s->ops_used += need;
@@ -474,13 +487,14 @@ static int launch_pass(qsim_state *s, const Pass &p) {
         for (int j = 0; j < p.geom.n_high; j++) hm |= 1ULL << p.geom.high[j];
         LaunchScope scope(s, p.kclass, (int)need, hm);
         const int threads = s->tile_threads; // 0: default for the tile size
-        e = launch_tile(cfg, s->amps, p.geom, d, (int)need, threads, from_zero_ket, s->zero_ket_amp);
+        e = launch_tile(cfg, s->amps, s->f32, p.geom, d, (int)need, threads, from_zero_ket, s->zero_ket_amp);
         break;
     }
     default: return fail(QSIM_ERR_ARG, "internal: unknown kernel class %d", p.kclass);
     }
     if (e != hipSuccess) return fail(QSIM_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
-    account(s, p.kclass, from_zero_ket ? p.bytes / 2 : p.bytes); // a generating pass only writes
+    const double scale = s->f32 ? 0.5 : 1.0; // the scheduler prices passes for 16-byte amplitudes
+    account(s, p.kclass, scale * (from_zero_ket ? p.bytes / 2 : p.bytes)); // a generating pass only writes
     return QSIM_OK;
 }
 
@@ -513,6 +527,17 @@ extern "C" int qsim_sync(qsim_state *s) {
 }
 
 // ---- amplitudes ----------------------------------------------------------------------------------------
+// `out` holds m doubles' worth of room and m floats in its second half: widen them front to back (element i is read
+// from byte 4m + 4i before byte 8i is written, and no later element starts below 8i + 8).
+static void widen_in_place(double *out, uint64_t m) {
+    const char *src = reinterpret_cast<const char *>(out) + 4 * m;
+    for (uint64_t i = 0; i < m; i++) {
+        float f;
+        memcpy(&f, src + 4 * i, 4);
+        out[i] = (double)f;
+    }
+}
+
 extern "C" int qsim_read(qsim_state *s, uint64_t first, uint64_t count, double *out) {
     if (!s || !out) return fail(QSIM_ERR_ARG, "NULL argument");
     const uint64_t N = 1ULL << s->n;
@@ -520,7 +545,15 @@ extern "C" int qsim_read(qsim_state *s, uint64_t first, uint64_t count, double *
     const int rc = qsim_sync(s);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(s->device));
-    if (count) HIP_TRY(hipMemcpy(out, s->amps + first, count * 16, hipMemcpyDeviceToHost));
+    if (!count) return QSIM_OK;
+    if (!s->f32) {
+        HIP_TRY(hipMemcpy(out, (const char *)s->amps + first * 16, count * 16, hipMemcpyDeviceToHost));
+        return QSIM_OK;
+    }
+    // fp32 state: the API stays double; copy into the second half of the output and widen in place, front to back
+    char *tmp = reinterpret_cast<char *>(out) + 8 * count;
+    HIP_TRY(hipMemcpy(tmp, (const char *)s->amps + first * 8, count * 8, hipMemcpyDeviceToHost));
+    widen_in_place(out, 2 * count);
     return QSIM_OK;
 }
 
@@ -531,7 +564,14 @@ extern "C" int qsim_write(qsim_state *s, uint64_t first, uint64_t count, const d
     const int rc = qsim_sync(s);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(s->device));
-    if (count) HIP_TRY(hipMemcpy(s->amps + first, in, count * 16, hipMemcpyHostToDevice));
+    if (!count) return QSIM_OK;
+    if (!s->f32) {
+        HIP_TRY(hipMemcpy((char *)s->amps + first * 16, in, count * 16, hipMemcpyHostToDevice));
+        return QSIM_OK;
+    }
+    std::vector<float> tmp(2 * count);
+    for (uint64_t i = 0; i < 2 * count; i++) tmp[i] = (float)in[i];
+    HIP_TRY(hipMemcpy((char *)s->amps + first * 8, tmp.data(), count * 8, hipMemcpyHostToDevice));
     return QSIM_OK;
 }
 
@@ -543,7 +583,7 @@ extern "C" int qsim_norm2(qsim_state *s, double *out) {
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipMemsetAsync(s->d_scalar, 0, 8, s->stream));
     LaunchCfg cfg{s->stream, s->grid_cap};
-    HIP_TRY(launch_norm2(cfg, s->amps, s->n, s->d_scalar));
+    HIP_TRY(launch_norm2(cfg, s->amps, s->f32, s->n, s->d_scalar));
     HIP_TRY(hipMemcpyAsync(out, s->d_scalar, 8, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return QSIM_OK;
@@ -578,7 +618,7 @@ extern "C" int qsim_sample(qsim_state *s, const double *randoms, long shots, uin
     double *d_part = nullptr;
     HIP_TRY(hipMalloc((void **)&d_part, nblocks * sizeof(double)));
     LaunchCfg cfg{s->stream, s->grid_cap};
-    hipError_t e = launch_block_prob(cfg, s->amps, s->n, bb, d_part);
+    hipError_t e = launch_block_prob(cfg, s->amps, s->f32, s->n, bb, d_part);
     std::vector<double> prefix(nblocks);
     if (e == hipSuccess) e = hipMemcpyAsync(prefix.data(), d_part, nblocks * sizeof(double), hipMemcpyDeviceToHost, s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
@@ -602,7 +642,13 @@ extern "C" int qsim_sample(qsim_state *s, const double *randoms, long shots, uin
         bool found = false;
         for (uint64_t b = lo; b < nblocks && !found; b++) { // normally one block; rounding can push it to the next
             if (b != cached) {
-                HIP_TRY(hipMemcpy(blk.data(), s->amps + b * bsize, bsize * 16, hipMemcpyDeviceToHost));
+                if (!s->f32) {
+                    HIP_TRY(hipMemcpy(blk.data(), (const char *)s->amps + b * bsize * 16, bsize * 16, hipMemcpyDeviceToHost));
+                } else {
+                    char *tmp = reinterpret_cast<char *>(blk.data()) + 8 * bsize;
+                    HIP_TRY(hipMemcpy(tmp, (const char *)s->amps + b * bsize * 8, bsize * 8, hipMemcpyDeviceToHost));
+                    widen_in_place(blk.data(), 2 * bsize);
+                }
                 cached = b;
             }
             double c = b ? prefix[b - 1] : 0.0;
@@ -622,7 +668,7 @@ extern "C" int qsim_pack_bits(qsim_state *s, const int *bits, int nbits, void *d
     for (int j = 0; j < nbits; j++)
         if (bits[j] < 0 || bits[j] >= s->n || (j && bits[j] <= bits[j - 1]))
             return fail(QSIM_ERR_ARG, "pack: bit positions must be ascending and inside the shard");
-    if (dst == (void *)s->amps) return fail(QSIM_ERR_ARG, "pack: dst must not alias the state");
+    if (dst == s->amps) return fail(QSIM_ERR_ARG, "pack: dst must not alias the state");
     int rc = qsim_flush(s);
     if (rc == QSIM_OK) rc = materialize_zero_ket(s);
     if (rc) return rc;
@@ -631,10 +677,10 @@ extern "C" int qsim_pack_bits(qsim_state *s, const int *bits, int nbits, void *d
     hipError_t e;
     {
         LaunchScope scope(s, QSIM_K_PACK);
-        e = launch_pack(cfg, s->amps, (double2 *)dst, s->n, bits, nbits);
+        e = launch_pack(cfg, s->amps, dst, s->f32, s->n, bits, nbits);
     }
     if (e != hipSuccess) return fail(QSIM_ERR_DEVICE, "pack launch failed: %s", hipGetErrorString(e));
-    account(s, QSIM_K_PACK, 32.0 * (double)(1ULL << s->n));
+    account(s, QSIM_K_PACK, 2.0 * (double)s->amp_bytes() * (double)(1ULL << s->n));
     return QSIM_OK;
 }
 

@@ -12,6 +12,7 @@
  *                          (quantum_simulator.c:67-73): "MEASUREMENT: <bits> (<index>)", drawn like :270-283
  *   QSIM_SHARDS=P          split the register over P = 2^p shards driven by this process: devices round-robin over the
  *                          visible GPUs (all on one GPU = virtual shards); QSIM_DUMP then writes LOGICAL order
+ *   QSIM_PRECISION=32      hold the amplitudes as fp32 complex like the CUDA variants (naive.cu:38); default 64
  *   QSIM_DEVICE, QSIM_FUSE, QSIM_TILE_BITS, QSIM_TILE_LOW_BITS, QSIM_TILE_MAX_OPS, QSIM_GRID_CAP, QSIM_PROFILE
  */
 #include <stdio.h>
@@ -119,7 +120,8 @@ int main(int argc, char *argv[]) {
     const int shards = (v = getenv("QSIM_SHARDS")) && *v ? atoi(v) : 1;
     if (shards > 1) return run_sharded(c, shards, t_start);
     const int device = (v = getenv("QSIM_DEVICE")) && *v ? atoi(v) : 0;
-    rc = qsim_create(&s, qsim_circuit_num_qubits(c), device);
+    const int f32 = (v = getenv("QSIM_PRECISION")) && atoi(v) == 32;
+    rc = f32 ? qsim_create_f32(&s, qsim_circuit_num_qubits(c), device) : qsim_create(&s, qsim_circuit_num_qubits(c), device);
     if (rc == QSIM_OK) rc = qsim_apply_env_options(s);
     if (rc == QSIM_OK) rc = qsim_run_circuit(s, c, 0, -1);
     if (rc == QSIM_OK) rc = qsim_sync(s);

@@ -56,25 +56,23 @@ struct LaunchCfg {
     int grid_cap; // 0 = one workgroup per work tile
 };
 
-// All launchers are asynchronous on cfg.stream and return the hipError_t of the launch.
-hipError_t launch_init(const LaunchCfg &cfg, double2 *v, int n, double amp0 = 1.0);
-hipError_t launch_gate1(const LaunchCfg &cfg, double2 *v, int n, int q, const M2 &U);
-hipError_t launch_phase(const LaunchCfg &cfg, double2 *v, int n, int q, double lr, double li);
-hipError_t launch_diag1_full(const LaunchCfg &cfg, double2 *v, int n, int q, double d0r, double d0i, double d1r,
-                             double d1i);
-hipError_t launch_cx(const LaunchCfg &cfg, double2 *v, int n, int control, int target);
-hipError_t launch_gate2(const LaunchCfg &cfg, double2 *v, int n, int q_hi, int q_lo, const M4 &U);
-// from_zero_ket: the state is a not-yet-written |0...0>; the pass generates it in LDS instead of loading it
-hipError_t launch_tile(const LaunchCfg &cfg, double2 *v, const TileGeom &g, const TileOp *d_ops, int n_ops, int threads,
-                       bool from_zero_ket, double amp0 = 1.0);
-hipError_t launch_norm2(const LaunchCfg &cfg, const double2 *v, int n, double *d_out /* zeroed */);
+// All launchers are asynchronous on cfg.stream and return the hipError_t of the launch.  `f32` selects the amplitude
+// precision of the state `v` points to: false = fp64 complex (16 B per amplitude), true = fp32 complex (8 B).
+hipError_t launch_init(const LaunchCfg &cfg, void *v, bool f32, int n, double amp0);
+hipError_t launch_gate1(const LaunchCfg &cfg, void *v, bool f32, int n, int q, const M2 &U);
+hipError_t launch_phase(const LaunchCfg &cfg, void *v, bool f32, int n, int q, double lr, double li);
+hipError_t launch_diag1_full(const LaunchCfg &cfg, void *v, bool f32, int n, int q, double d0r, double d0i, double d1r, double d1i);
+hipError_t launch_cx(const LaunchCfg &cfg, void *v, bool f32, int n, int control, int target);
+hipError_t launch_gate2(const LaunchCfg &cfg, void *v, bool f32, int n, int q_hi, int q_lo, const M4 &U);
+// from_zero_ket: the state is a not-yet-written basis state; the pass generates it in LDS instead of loading it
+hipError_t launch_tile(const LaunchCfg &cfg, void *v, bool f32, const TileGeom &g, const TileOp *d_ops, int n_ops, int threads,
+                       bool from_zero_ket, double amp0);
+hipError_t launch_norm2(const LaunchCfg &cfg, const void *v, bool f32, int n, double *d_out /* zeroed */);
 // d_out[b] = sum of |a|^2 over amplitudes [b << block_bits, (b+1) << block_bits), fixed summation order
-hipError_t launch_block_prob(const LaunchCfg &cfg, const double2 *v, int n, int block_bits, double *d_out);
+hipError_t launch_block_prob(const LaunchCfg &cfg, const void *v, bool f32, int n, int block_bits, double *d_out);
 // out[dst] = in[src]: dst = (block << (n-p)) | rest, where block = the p bits of src at positions
 // `bits` (ascending) and rest = the remaining n-p bits of src in order.
-hipError_t launch_pack(const LaunchCfg &cfg, const double2 *in, double2 *out, int n, const int *bits, int p);
-
-int tile_lds_bytes(int tile_bits, int n_high);
+hipError_t launch_pack(const LaunchCfg &cfg, const void *in, void *out, bool f32, int n, const int *bits, int p);
 
 } // namespace qsim
 #endif

@@ -139,10 +139,17 @@ class Simulator:
     """One state vector resident on one GPU."""
 
     def __init__(self, num_q: int, device: int = 0, *, fuse: Optional[int] = None, profile: bool = False,
-                 external_ptr: Optional[int] = None, **options):
+                 external_ptr: Optional[int] = None, precision: int = 64, **options):
         self._h = c_void_p()
         lib = _lib.load()
-        if external_ptr is None:
+        if precision not in (32, 64):
+            raise ValueError("precision must be 64 (fp64 complex, the parity configuration) or 32")
+        self.precision = precision
+        if precision == 32:
+            if external_ptr is not None:
+                raise ValueError("external buffers are fp64 only")
+            check(lib.qsim_create_f32(byref(self._h), num_q, device))
+        elif external_ptr is None:
             check(lib.qsim_create(byref(self._h), num_q, device))
         else:
             check(lib.qsim_create_external(byref(self._h), num_q, device, c_void_p(external_ptr)))

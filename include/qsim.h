@@ -93,6 +93,13 @@ const char *qsim_last_error(void);
 /* Allocates 2^num_q amplitudes on `device` and sets |0...0>.  Replaces the malloc + init loop of the
  * `qubit` statement (quantum_simulator.c:168-177) and init_state_vector (quantum_simulator_naive.cu:64-70). */
 int qsim_create(qsim_state **out, int num_q, int device);
+/* Same, with the amplitudes held as fp32 complex (8 bytes each): the precision of the reference's CUDA variants
+ * (`cuFloatComplex`, quantum_simulator_naive.cu:38,64-70).  Half the HBM bytes per pass and one more qubit per GPU;
+ * every entry point keeps its double-typed interface (matrices are rounded once when a pass is built, qsim_read /
+ * qsim_write convert), sums (norm, sampling) still accumulate in fp64.  Not the parity configuration: results agree
+ * with quantum_simulator.c to fp32 rounding (~1e-6 per amplitude), not to 1e-10.  Clusters are fp64 only. */
+int qsim_create_f32(qsim_state **out, int num_q, int device);
+int qsim_precision_bits(const qsim_state *s); /* 64 or 32; -1 for NULL */
 /* Same, on caller-owned device memory of 16<<num_q bytes (e.g. a torch tensor's storage). */
 int qsim_create_external(qsim_state **out, int num_q, int device, void *device_amps);
 void qsim_destroy(qsim_state *s);

@@ -14,6 +14,7 @@ QSIM_OK, ERR_ARG, ERR_ALLOC, ERR_DEVICE, ERR_OPEN, ERR_PARSE = range(6)
 GATE_U1, GATE_CX, GATE_U2, GATE_U3 = 1, 2, 3, 4
 OPT_FUSE, OPT_PROFILE, OPT_TILE_BITS, OPT_TILE_LOW_BITS, OPT_MAX_PENDING, OPT_TILE_MAX_OPS, OPT_GRID_CAP, OPT_TILE_THREADS = range(1, 9)
 OPT_TILE_PAD_FROM = 9
+OPT_DEBUG_SKIP_OPS = 10
 K_NAMES = ("init", "gate1", "gate1_lo", "phase", "cx", "gate2", "tile", "pack")
 K_COUNT = len(K_NAMES)
 

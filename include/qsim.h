@@ -58,7 +58,9 @@ enum {
     QSIM_OPT_TILE_MAX_OPS = 6, /* upper bound on fused blocks per tile pass (default 32) */
     QSIM_OPT_GRID_CAP = 7,     /* 0: one workgroup per work tile; >0: at most that many workgroups (grid-stride loop) */
     QSIM_OPT_TILE_PAD_FROM = 9,/* first index bit used to fill unused high slots of a tile (default 10) */
-    QSIM_OPT_TILE_THREADS = 8  /* threads per tile workgroup: 0 auto (256 below 2^12 amplitudes, else 512), 256, 512, 1024 */
+    QSIM_OPT_TILE_THREADS = 8, /* threads per tile workgroup: 0 auto (256 below 2^12 amplitudes, else 512), 256, 512, 1024 */
+    QSIM_OPT_DEBUG_SKIP_OPS = 10 /* measurement aid, default 0: 1 = tile passes move their tiles HBM -> LDS -> HBM but apply
+                                  * no blocks (amplitudes are then WRONG); splits a pass's memory time from its compute time */
 };
 
 /* Kernel classes reported by qsim_get_stats. */

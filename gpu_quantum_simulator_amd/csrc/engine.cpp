@@ -365,8 +365,50 @@ static inline int local_bit(const TileGeom &g, int q) {
 
 // FusedOp -> device TileOp.  Returns false when a qubit is outside the tile or the block cannot be expressed
 // (a 3-qubit block with more than 4 entries per row; merge_sparse never produces one).
+// A block with qubits outside the tile (FusedOp::sel_mask): a tile-uniform factor when none of its qubits is inside,
+// else a 2x2 on its one inside qubit with two coefficient banks picked by the outside qubit's bit of the tile base.
+static bool to_selected_tile_op(const TileGeom &g, const FusedOp &op, TileOp &t) {
+    const int k = op.nq(), D = op.dim();
+    const int qs[3] = {op.q_hi, op.q_lo, op.q_lo2};
+    auto is1 = [&](const cd &z) { return z.real() == 1.0 && z.imag() == 0.0; };
+    auto is0 = [&](const cd &z) { return z.real() == 0.0 && z.imag() == 0.0; };
+    if (op.is_scalar_in_tile()) {
+        if (k > 2) return false;
+        t.kind = TOP_SCALE;
+        t.nq = k;
+        t.b[0] = qs[0];
+        t.b[1] = k == 2 ? qs[1] : -1;
+        for (int r = 0; r < D; r++) { t.re[r] = op.m[(D + 1) * r].real(); t.im[r] = op.m[(D + 1) * r].imag(); }
+        return true;
+    }
+    if (k != 2 || __builtin_popcountll(op.sel_mask) != 1) return false;
+    const bool sel_is_hi = (op.sel_mask >> op.q_hi) & 1ULL;
+    const int in_q = sel_is_hi ? op.q_lo : op.q_hi, sel_q = sel_is_hi ? op.q_hi : op.q_lo;
+    const int lb = local_bit(g, in_q);
+    if (lb < 0 || local_bit(g, sel_q) >= 0) return false;
+    t.kind = TOP_G1;
+    t.nq = 1;
+    t.b[0] = lb;
+    t.sel = (uint32_t)sel_q + 1u;
+    for (int v = 0; v < 2; v++) {
+        bool ident = true;
+        for (int r = 0; r < 2; r++)
+            for (int c = 0; c < 2; c++) {
+                // row/column index of the 4x4: (q_hi, q_lo), most significant first
+                const int R = sel_is_hi ? (2 * v + r) : (2 * r + v), C = sel_is_hi ? (2 * v + c) : (2 * c + v);
+                const cd z = op.m[4 * R + C];
+                t.re[4 * v + 2 * r + c] = z.real();
+                t.im[4 * v + 2 * r + c] = z.imag();
+                ident = ident && (r == c ? is1(z) : is0(z));
+            }
+        if (ident) t.meta |= 1 << v;
+    }
+    return true;
+}
+
 static bool to_tile_op(const TileGeom &g, const FusedOp &op, TileOp &t, int amp_shift = 4) {
     memset(&t, 0, sizeof t);
+    if (op.sel_mask) return to_selected_tile_op(g, op, t);
     const int k = op.nq(), D = op.dim();
     const int qs[3] = {op.q_hi, op.q_lo, op.q_lo2}; // most significant first
     t.nq = k;
@@ -492,7 +534,13 @@ static int launch_pass(qsim_state *s, const Pass &p) {
         for (int j = 0; j < p.geom.n_high; j++) hm |= 1ULL << p.geom.high[j];
         LaunchScope scope(s, p.kclass, (int)need, hm);
         const int threads = s->tile_threads; // 0: default for the tile size
-        e = launch_tile(cfg, s->amps, s->f32, p.geom, d, s->debug_skip_ops ? 0 : (int)need, threads, from_zero_ket, s->zero_ket_amp);
+        if (s->debug_skip_ops) {
+            TileGeom bare = p.geom;
+            bare.n_scale = 0;
+            e = launch_tile(cfg, s->amps, s->f32, bare, d, 0, threads, from_zero_ket, s->zero_ket_amp);
+        } else {
+            e = launch_tile(cfg, s->amps, s->f32, p.geom, d, (int)need, threads, from_zero_ket, s->zero_ket_amp);
+        }
         break;
     }
     default: return fail(QSIM_ERR_ARG, "internal: unknown kernel class %d", p.kclass);

@@ -27,14 +27,17 @@ struct M4 { double re[16], im[16]; };
 //              instruction count.)
 //              Most fused clusters of Clifford+T-like circuits are permutations times phases or two independent
 //              2x2 blocks, and so are products of neighbouring ones on <= 3 qubits (Scheduler::merge_sparse).
-enum : int32_t { TOP_G1 = 1, TOP_G2 = 2, TOP_DIAG1 = 3, TOP_SP = 4 };
+enum : int32_t { TOP_G1 = 1, TOP_G2 = 2, TOP_DIAG1 = 3, TOP_SP = 4, TOP_SCALE = 5 };
 struct TileOp {
     int32_t kind;
     int32_t nq;       // qubits of the block (1..3)
     int32_t b[3];     // tile-local bits, ascending
     int32_t terms;    // TOP_SP: entries per row (1, 2, 4)
-    int32_t meta;     // see above
-    uint32_t pad;
+    int32_t meta;     // see above; selected TOP_G1: bit v set = bank v is the identity (the block is skipped on those tiles)
+    uint32_t sel;     // TOP_G1: 0, or 1 + the GLOBAL index bit (outside the tile) that selects the coefficient bank:
+                      // re/im[0..3] where that bit of the tile's base index is 0, re/im[4..7] where it is 1.
+                      // TOP_SCALE (tile-uniform factor, applied while the tile is staged in): b[0] (and b[1], or -1) are
+                      // GLOBAL index bits outside the tile; the factor is re/im[bit(b[0])] or re/im[2*bit(b[0]) + bit(b[1])]
     uint32_t off[32];    // TOP_SP: LDS BYTE offset of entry e's operand slot
     uint32_t rowoff[8];  // TOP_SP: LDS BYTE offset of row r's slot
     double re[32];
@@ -49,6 +52,7 @@ struct TileGeom {
     int32_t n_high;             // B - L
     int32_t n;                  // qubits in this state (shard)
     int32_t high[kMaxTileHigh]; // ascending global bit of tile-local bit L+j
+    int32_t n_scale;            // leading entries of the pass's op list that are TOP_SCALE factors, not blocks
 };
 
 struct LaunchCfg {

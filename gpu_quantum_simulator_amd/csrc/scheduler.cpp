@@ -33,6 +33,22 @@ int FusedOp::max_row_nnz() const {
     return best;
 }
 
+uint64_t FusedOp::selector_mask() const {
+    if (kind == OP_CX) return 1ULL << q_hi; // the control
+    const int k = nq(), d = dim();
+    const int qs[3] = {q_hi, q_lo, q_lo2};
+    uint64_t out = 0;
+    for (int a = 0; a < k; a++) {
+        const int bit = 1 << (k - 1 - a); // position of qs[a] in the row/column index
+        bool ok = true;
+        for (int r = 0; r < d && ok; r++)
+            for (int c = 0; c < d; c++)
+                if (((r ^ c) & bit) && !is_zero(m[d * r + c])) { ok = false; break; }
+        if (ok) out |= 1ULL << qs[a];
+    }
+    return out;
+}
+
 // EXACT identity only: the reference's isIdentity tolerance of 1e-3 (quantum_simulator_4x4.cu:247-250)
 // silently drops and reorders small rotations.
 bool FusedOp::is_identity() const {
@@ -110,6 +126,19 @@ void Scheduler::add_1q(const cd U[4], int q) {
         open_[q] = (int)pool_.size() - 1;
         return;
     }
+    // Level 3 keeps a pair cluster block-diagonal in a qubit for as long as it can: such a cluster can run in passes
+    // whose tile does not contain that qubit.  A gate that would mix the qubit's halves starts a new cluster instead
+    // (inside one pass the two are merged again by merge_sparse).
+    if (cfg_.fuse >= 3 && cfg_.selectors && pool_[idx].kind == OP_G2 && (!is_zero(U[1]) || !is_zero(U[2])) &&
+        (pool_[idx].selector_mask() >> q & 1ULL)) {
+        close(idx);
+        FusedOp op;
+        op.kind = OP_G1; op.q_hi = q; op.gates = 1;
+        std::copy(U, U + 4, op.m);
+        pool_.push_back(op);
+        open_[q] = (int)pool_.size() - 1;
+        return;
+    }
     FusedOp &c = pool_[idx];
     c.gates++;
     if (c.kind == OP_G1) {
@@ -161,6 +190,16 @@ void Scheduler::fold_2q(const cd U[16], int q_hi, int q_lo, uint32_t gates) {
     // a cluster shared with a third qubit has to run first
     if (ia >= 0 && pool_[ia].kind == OP_G2) { close(ia); ia = -1; }
     if (ib >= 0 && pool_[ib].kind == OP_G2) { close(ib); ib = -1; }
+    if (cfg_.fuse >= 3 && cfg_.selectors) {
+        // same idea when the pair cluster is created: a pending 1-qubit product that is not diagonal would destroy
+        // the block-diagonal structure U has in that qubit (e.g. the control of a CX) — let it run on its own
+        FusedOp probe;
+        probe.kind = OP_G2; probe.q_hi = q_hi; probe.q_lo = q_lo;
+        std::copy(U, U + 16, probe.m);
+        const uint64_t sel = probe.selector_mask();
+        if (ia >= 0 && (sel >> q_hi & 1ULL) && !pool_[ia].is_diag()) { close(ia); ia = -1; }
+        if (ib >= 0 && (sel >> q_lo & 1ULL) && !pool_[ib].is_diag()) { close(ib); ib = -1; }
+    }
     FusedOp op;
     op.kind = OP_G2; op.q_hi = q_hi; op.q_lo = q_lo; op.gates = gates;
     const cd *a = kI2, *b = kI2;
@@ -214,21 +253,35 @@ void Scheduler::single_op_pass(const FusedOp &op, const PassSink &sink) const {
             p.bytes = 2 * S;
             sink(std::move(p));
         } else {
-            tile_pass(p.ops, sink);
+            tile_pass(p.ops, op.qmask(), sink);
         }
     }
 }
 
-void Scheduler::tile_pass(const std::vector<FusedOp> &ops, const PassSink &sink) const {
+void Scheduler::tile_pass(const std::vector<FusedOp> &ops, uint64_t hset, const PassSink &sink) const {
     const int B = std::min(cfg_.tile_bits, cfg_.n);
     const int L = std::min(cfg_.tile_low_bits, B);
+    const uint64_t lowmask = (1ULL << L) - 1ULL;
     Pass p;
     p.kclass = QSIM_K_TILE;
-    p.ops = ops;
     p.bytes = 32.0 * (double)(1ULL << cfg_.n);
-    if (cfg_.merge && p.ops.size() > 1) merge_sparse(p.ops);
-    uint64_t high = 0;
-    for (const FusedOp &op : p.ops) high |= op.qmask() & ~((1ULL << L) - 1ULL);
+    // `hset`: the high qubits the blocks NEED in the tile.  Qubits a block is merely block-diagonal in may stay outside
+    // (they select a sub-block per tile); while slots are free they are taken in anyway, most used first, because a
+    // block that lies entirely inside the tile can be merged with its neighbours.
+    uint64_t high = hset & ~lowmask;
+    {
+        int uses[64] = {0};
+        for (const FusedOp &op : ops)
+            for (uint64_t rest = op.qmask() & ~lowmask & ~high; rest; rest &= rest - 1) uses[__builtin_ctzll(rest)]++;
+        while (__builtin_popcountll(high) < B - L) {
+            int best = -1;
+            for (int b = L; b < cfg_.n; b++)
+                if (uses[b] > 0 && (best < 0 || uses[b] > uses[best])) best = b;
+            if (best < 0) break;
+            high |= 1ULL << best;
+            uses[best] = 0;
+        }
+    }
     // unused slots are filled with free bits starting at pad_from, wrapping around to the low end.  Measured at
     // n = 30 (tools/pad_sweep.py): with three or four genuinely high qubits in the tile, padding with the lowest
     // bits (longest contiguous runs) costs up to 8.6 ms per pass against 6.8 ms when bits 10.. are used; 10 had the
@@ -242,6 +295,31 @@ void Scheduler::tile_pass(const std::vector<FusedOp> &ops, const PassSink &sink)
     p.geom.n_high = 0;
     for (int b = L; b < cfg_.n; b++)
         if (high >> b & 1ULL) p.geom.high[p.geom.n_high++] = b;
+
+    // Blocks with every qubit outside the tile are tile-uniform factors: they commute with everything else in the pass
+    // (nothing in it can touch those qubits except other blocks that are block-diagonal in them) and go to the front,
+    // one entry per qubit set.
+    const uint64_t inside = lowmask | high;
+    std::vector<FusedOp> scalars, blocks;
+    for (FusedOp op : ops) {
+        op.sel_mask = op.qmask() & ~inside;
+        if (!op.is_scalar_in_tile()) { blocks.push_back(op); continue; }
+        bool folded = false;
+        for (FusedOp &sc : scalars)
+            if (sc.kind == op.kind && sc.q_hi == op.q_hi && sc.q_lo == op.q_lo) {
+                const int d = op.dim();
+                for (int r = 0; r < d; r++) sc.m[(d + 1) * r] = op.m[(d + 1) * r] * sc.m[(d + 1) * r];
+                sc.gates += op.gates;
+                folded = true;
+                break;
+            }
+        if (!folded) scalars.push_back(op);
+    }
+    if (cfg_.merge && blocks.size() > 1) merge_sparse(blocks);
+    p.geom.n_scale = (int)scalars.size();
+    p.ops = std::move(scalars);
+    p.ops.insert(p.ops.end(), blocks.begin(), blocks.end());
+    if (p.ops.empty()) return;
     sink(std::move(p));
 }
 
@@ -256,8 +334,11 @@ void Scheduler::build_passes(const PassSink &sink) {
     const uint64_t lowmask = (1ULL << L) - 1ULL;
     const uint64_t all = cfg_.n >= 64 ? ~0ULL : ((1ULL << cfg_.n) - 1ULL);
     const size_t m = closed_.size();
-    std::vector<uint64_t> qm(m);
-    for (size_t i = 0; i < m; i++) qm[i] = closed_[i].qmask();
+    std::vector<uint64_t> qm(m), must(m); // all qubits of a block (ordering); the ones that have to be tile qubits
+    for (size_t i = 0; i < m; i++) {
+        qm[i] = closed_[i].qmask();
+        must[i] = cfg_.selectors ? (qm[i] & ~closed_[i].selector_mask()) : qm[i];
+    }
     std::vector<char> done(m, 0), trial;
     size_t first = 0;
     std::vector<FusedOp> group;
@@ -273,7 +354,7 @@ void Scheduler::build_passes(const PassSink &sink) {
         for (size_t i = from; i < to; i++) {
             if (dn[i]) continue;
             if (!(qm[i] & blocked)) {
-                const int need = __builtin_popcountll(qm[i] & ~lowmask & ~hset);
+                const int need = __builtin_popcountll(must[i] & ~lowmask & ~hset);
                 if (used + need <= kmax) {
                     if (cands) cands->push_back({(long)i, need});
                     if (need < best.need) {
@@ -294,7 +375,7 @@ void Scheduler::build_passes(const PassSink &sink) {
             const Cand c = scan(dn, from, to, hset, nullptr);
             if (c.idx < 0) break;
             dn[(size_t)c.idx] = 1;
-            hset |= qm[(size_t)c.idx] & ~lowmask;
+            hset |= must[(size_t)c.idx] & ~lowmask;
             cnt++;
         }
         return cnt;
@@ -319,12 +400,12 @@ void Scheduler::build_passes(const PassSink &sink) {
                 for (size_t t = 0; t < tries; t++) {
                     trial = done;
                     trial[(size_t)cands[t].idx] = 1;
-                    const int score = rollout(trial, first, end, hset | (qm[(size_t)cands[t].idx] & ~lowmask), (int)group.size() + 1);
+                    const int score = rollout(trial, first, end, hset | (must[(size_t)cands[t].idx] & ~lowmask), (int)group.size() + 1);
                     if (score > best_score) { best_score = score; pick = cands[t]; }
                 }
             }
             group.push_back(closed_[(size_t)pick.idx]);
-            hset |= qm[(size_t)pick.idx] & ~lowmask;
+            hset |= must[(size_t)pick.idx] & ~lowmask;
             done[(size_t)pick.idx] = 1;
         }
         if (group.empty()) { // cannot happen while kmax >= 2; keep the scheduler total anyway
@@ -333,7 +414,7 @@ void Scheduler::build_passes(const PassSink &sink) {
         } else if (group.size() == 1) {
             single_op_pass(group[0], sink);
         } else {
-            tile_pass(group, sink);
+            tile_pass(group, hset, sink);
         }
     }
 }
@@ -373,15 +454,20 @@ void Scheduler::merge_sparse(std::vector<FusedOp> &ops) const {
     std::vector<FusedOp> rem(ops), next, out;
     while (!rem.empty()) {
         FusedOp cur = rem[0];
+        if (cur.sel_mask) { // a block selected by out-of-tile bits is emitted as it is
+            out.push_back(cur);
+            rem.erase(rem.begin());
+            continue;
+        }
         uint64_t blocked = 0;
         next.clear();
         for (size_t i = 1; i < rem.size(); i++) {
             const FusedOp &op = rem[i];
-            const uint64_t qm = op.qmask();
+            const uint64_t qm = op.qmask() & ~op.sel_mask; // what it touches inside the tile
             if (qm & blocked) { blocked |= qm; next.push_back(op); continue; }
             const uint64_t un = cur.qmask() | qm;
             bool merged = false;
-            if (__builtin_popcountll(un) <= kMaxQ && cur.kind != OP_CX && op.kind != OP_CX &&
+            if (!op.sel_mask && __builtin_popcountll(un) <= kMaxQ && cur.kind != OP_CX && op.kind != OP_CX &&
                 cur.max_row_nnz() * op.max_row_nnz() <= 2 * kMaxNnz) {
                 int qs[3], k = 0;
                 for (int b = 63; b >= 0; b--)

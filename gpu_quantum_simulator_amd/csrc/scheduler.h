@@ -30,6 +30,10 @@ struct FusedOp {
     int q_lo2 = -1; // OP_G3: lowest qubit
     cd m[64];       // row-major 2x2 / 4x4 / 8x8; index bits = (q_hi, q_lo[, q_lo2]), most significant first
     uint32_t gates = 0;
+    // Set when the op is emitted into a tile pass: those of its qubits that are NOT in the pass's tile.  The op is
+    // block-diagonal in each of them (selector_mask), so per tile it reduces to the sub-block picked by those bits of
+    // the tile's base index: a smaller block on the in-tile qubits, or a plain factor when none is left.
+    uint64_t sel_mask = 0;
 
     int nq() const { return kind == OP_G1 ? 1 : kind == OP_G3 ? 3 : 2; }
     int dim() const { return 1 << nq(); }
@@ -42,6 +46,8 @@ struct FusedOp {
     int max_row_nnz() const; // exact-zero structure
     bool is_diag() const;
     bool is_identity() const;
+    uint64_t selector_mask() const; // qubits the matrix is block-diagonal in (exact zeros): it never mixes their 0 and 1 halves
+    bool is_scalar_in_tile() const { return sel_mask != 0 && sel_mask == qmask(); }
 };
 
 struct Pass {
@@ -62,6 +68,7 @@ struct SchedConfig {
     int merge = 1;     // level 3: merge neighbouring blocks of a pass into sparse <=3-qubit blocks
     int rollout = 8;   // level 3: candidates tried (each by greedily finishing the pass) when a new qubit must be admitted; 0 = off
     int pad_from = 10; // first bit tried when unused tile slots are filled (below tile_low_bits: tile_low_bits)
+    int selectors = 0; // level 3: a block may run in a pass whose tile lacks qubits it is block-diagonal in
 };
 
 class Scheduler {
@@ -95,7 +102,7 @@ class Scheduler {
     void fold_2q(const cd U[16], int q_hi, int q_lo, uint32_t gates);
     void build_passes(const PassSink &sink);
     void single_op_pass(const FusedOp &op, const PassSink &sink) const;
-    void tile_pass(const std::vector<FusedOp> &ops, const PassSink &sink) const;
+    void tile_pass(const std::vector<FusedOp> &ops, uint64_t hset, const PassSink &sink) const;
     void merge_sparse(std::vector<FusedOp> &ops) const;
 };
 

@@ -177,6 +177,17 @@ def test_tile_passes_respect_geometry_limits():
     for ops in by_pass.values():
         assert len(ops) <= 5
         if ops[0][1] == "tile":
-            high = {q for o in ops for q in o[3] if q >= 6}
+            # a block may leave qubits it is block-diagonal in outside the tile (they select a sub-block per tile);
+            # every other high qubit needs one of the 4 slots
+            def mixing(qs, U):
+                k = len(qs)
+                out = set()
+                for a, q in enumerate(qs):  # qs: most significant first
+                    bit = 1 << (k - 1 - a)
+                    r, c = np.nonzero(U)
+                    if np.any((r ^ c) & bit):
+                        out.add(q)
+                return out
+            high = {q for o in ops for q in mixing(o[3], o[4]) if q >= 6}
             assert len(high) <= 4
             assert all(len(o[3]) <= 3 and (o[4] != 0).sum(axis=1).max() <= (4 if len(o[3]) == 3 else 4) for o in ops)

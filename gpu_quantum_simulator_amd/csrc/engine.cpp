@@ -363,83 +363,53 @@ static inline int local_bit(const TileGeom &g, int q) {
     return -1;
 }
 
-// FusedOp -> device TileOp.  Returns false when a qubit is outside the tile or the block cannot be expressed
-// (a 3-qubit block with more than 4 entries per row; merge_sparse never produces one).
-// A block with qubits outside the tile (FusedOp::sel_mask): a tile-uniform factor when none of its qubits is inside,
-// else a 2x2 on its one inside qubit with two coefficient banks picked by the outside qubit's bit of the tile base.
-static bool to_selected_tile_op(const TileGeom &g, const FusedOp &op, TileOp &t) {
-    const int k = op.nq(), D = op.dim();
-    const int qs[3] = {op.q_hi, op.q_lo, op.q_lo2};
-    auto is1 = [&](const cd &z) { return z.real() == 1.0 && z.imag() == 0.0; };
-    auto is0 = [&](const cd &z) { return z.real() == 0.0 && z.imag() == 0.0; };
-    if (op.is_scalar_in_tile()) {
-        if (k > 2) return false;
-        t.kind = TOP_SCALE;
-        t.nq = k;
-        t.b[0] = qs[0];
-        t.b[1] = k == 2 ? qs[1] : -1;
-        for (int r = 0; r < D; r++) { t.re[r] = op.m[(D + 1) * r].real(); t.im[r] = op.m[(D + 1) * r].imag(); }
-        return true;
-    }
-    if (k != 2 || __builtin_popcountll(op.sel_mask) != 1) return false;
-    const bool sel_is_hi = (op.sel_mask >> op.q_hi) & 1ULL;
-    const int in_q = sel_is_hi ? op.q_lo : op.q_hi, sel_q = sel_is_hi ? op.q_hi : op.q_lo;
-    const int lb = local_bit(g, in_q);
-    if (lb < 0 || local_bit(g, sel_q) >= 0) return false;
-    t.kind = TOP_G1;
-    t.nq = 1;
-    t.b[0] = lb;
-    t.sel = (uint32_t)sel_q + 1u;
-    for (int v = 0; v < 2; v++) {
-        bool ident = true;
-        for (int r = 0; r < 2; r++)
-            for (int c = 0; c < 2; c++) {
-                // row/column index of the 4x4: (q_hi, q_lo), most significant first
-                const int R = sel_is_hi ? (2 * v + r) : (2 * r + v), C = sel_is_hi ? (2 * v + c) : (2 * c + v);
-                const cd z = op.m[4 * R + C];
-                t.re[4 * v + 2 * r + c] = z.real();
-                t.im[4 * v + 2 * r + c] = z.imag();
-                ident = ident && (r == c ? is1(z) : is0(z));
-            }
-        if (ident) t.meta |= 1 << v;
-    }
-    return true;
-}
-
-static bool to_tile_op(const TileGeom &g, const FusedOp &op, TileOp &t, int amp_shift = 4) {
+// TileBlock -> device TileOp.  Returns false when a qubit is on the wrong side of the tile or the block cannot be
+// expressed (a 3-qubit block with more than 4 entries per row; Scheduler::merge_blocks never produces one).
+static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, int amp_shift = 4) {
     memset(&t, 0, sizeof t);
-    if (op.sel_mask) return to_selected_tile_op(g, op, t);
-    const int k = op.nq(), D = op.dim();
-    const int qs[3] = {op.q_hi, op.q_lo, op.q_lo2}; // most significant first
+    const int k = blk.nq, D = blk.dim(), NB = blk.banks();
+    if (k > 3 || blk.ns > 2) return false;
     t.nq = k;
+    t.nsel = blk.ns;
+    for (int a = 0; a < blk.ns; a++) {
+        if (local_bit(g, blk.s[a]) >= 0 || blk.s[a] < 0 || blk.s[a] >= g.n) return false; // selectors lie outside the tile
+        t.selbit[a] = blk.s[a];
+    }
     for (int a = 0; a < k; a++) {
-        const int lb = local_bit(g, qs[k - 1 - a]); // ascending
+        const int lb = local_bit(g, blk.q[k - 1 - a]); // ascending
         if (lb < 0) return false;
         t.b[a] = lb;
     }
-    auto nz = [&](int r, int c) { return op.m[D * r + c].real() != 0.0 || op.m[D * r + c].imag() != 0.0; };
+    auto nz = [&](int v, int r, int c) { const cd &z = blk.bank[v][D * r + c]; return z.real() != 0.0 || z.imag() != 0.0; };
     auto is1 = [&](const cd &z) { return z.real() == 1.0 && z.imag() == 0.0; };
-    int maxnnz = 0;
-    for (int r = 0; r < D; r++) {
-        int cnt = 0;
-        for (int c = 0; c < D; c++) cnt += nz(r, c);
-        maxnnz = cnt > maxnnz ? cnt : maxnnz;
+    for (int v = 0; v < NB; v++)
+        if (blk.bank_is_identity(v)) t.ident |= 1 << v;
+    if (k == 0) { // tile-uniform factor
+        if (blk.ns == 0) return false;
+        t.kind = TOP_SCALE;
+        for (int v = 0; v < NB; v++) { t.re[v][0] = blk.bank[v][0].real(); t.im[v][0] = blk.bank[v][0].imag(); }
+        return true;
     }
+    const int maxnnz = blk.max_row_nnz();
     if (k == 1) {
-        if (maxnnz == 1 && nz(0, 0)) { // diagonal
-            t.kind = TOP_DIAG1;
-            t.re[0] = op.m[0].real(); t.im[0] = op.m[0].imag();
-            t.re[1] = op.m[3].real(); t.im[1] = op.m[3].imag();
-            t.meta = is1(op.m[0]) ? 1 : 0;
-        } else {
-            t.kind = TOP_G1;
-            for (int e = 0; e < 4; e++) { t.re[e] = op.m[e].real(); t.im[e] = op.m[e].imag(); }
+        bool diag = true;
+        for (int v = 0; v < NB; v++) diag = diag && !nz(v, 0, 1) && !nz(v, 1, 0);
+        t.kind = diag ? TOP_DIAG1 : TOP_G1;
+        for (int v = 0; v < NB; v++) {
+            if (diag) {
+                t.re[v][0] = blk.bank[v][0].real(); t.im[v][0] = blk.bank[v][0].imag();
+                t.re[v][1] = blk.bank[v][3].real(); t.im[v][1] = blk.bank[v][3].imag();
+                t.meta[v] = is1(blk.bank[v][0]) ? 1 : 0;
+            } else {
+                for (int e = 0; e < 4; e++) { t.re[v][e] = blk.bank[v][e].real(); t.im[v][e] = blk.bank[v][e].imag(); }
+            }
         }
         return true;
     }
     if (k == 2 && maxnnz > 2) { // dense 4x4: register form
         t.kind = TOP_G2;
-        for (int e = 0; e < 16; e++) { t.re[e] = op.m[e].real(); t.im[e] = op.m[e].imag(); }
+        for (int v = 0; v < NB; v++)
+            for (int e = 0; e < 16; e++) { t.re[v][e] = blk.bank[v][e].real(); t.im[v][e] = blk.bank[v][e].imag(); }
         return true;
     }
     if (maxnnz > 4) return false;
@@ -447,26 +417,27 @@ static bool to_tile_op(const TileGeom &g, const FusedOp &op, TileOp &t, int amp_
     t.kind = TOP_SP;
     t.terms = T;
     // LDS BYTE offset of a slot code (bit a of the code sits at tile-local bit b[a]), already passed through the
-    // kernel's layout swizzle (kernels.hip sw_slot: unit bits 0..3 ^= slot bit 4; linear, so it commutes with the
+    // kernel's layout swizzle (kernels_impl.inc sw_slot: unit bits 0..3 ^= slot bit 4; linear, so it commutes with the
     // XOR the kernel combines it with)
     auto slot_off = [&](int code) {
         uint32_t o = 0;
         for (int a = 0; a < k; a++) o |= (uint32_t)((code >> a) & 1) << t.b[a];
         return o ^ (((o >> 4) & 1u) * 15u);
     };
-    for (int r = 0; r < D; r++) {
-        t.rowoff[r] = slot_off(r) << amp_shift;
-        int j = 0;
-        for (int c = 0; c < D; c++)
-            if (nz(r, c)) {
-                const int e = r * T + j++;
-                t.off[e] = slot_off(c) << amp_shift;
-                t.re[e] = op.m[D * r + c].real();
-                t.im[e] = op.m[D * r + c].imag();
-            }
-        if (j == 1 && nz(r, r) && is1(op.m[D * r + r])) t.meta |= 1 << r; // identity row: no traffic at all
-        for (; j < T; j++) t.off[r * T + j] = slot_off(r) << amp_shift; // pad: zero coefficient on the row's own slot
-    }
+    for (int r = 0; r < D; r++) t.rowoff[r] = slot_off(r) << amp_shift;
+    for (int v = 0; v < NB; v++)
+        for (int r = 0; r < D; r++) {
+            int j = 0;
+            for (int c = 0; c < D; c++)
+                if (nz(v, r, c)) {
+                    const int e = r * T + j++;
+                    t.off[v][e] = slot_off(c) << amp_shift;
+                    t.re[v][e] = blk.bank[v][D * r + c].real();
+                    t.im[v][e] = blk.bank[v][D * r + c].imag();
+                }
+            if (j == 1 && nz(v, r, r) && is1(blk.bank[v][D * r + r])) t.meta[v] |= 1 << r; // identity row: no traffic at all
+            for (; j < T; j++) t.off[v][r * T + j] = slot_off(r) << amp_shift; // pad: zero coefficient on the row's own slot
+        }
     return true;
 }
 
@@ -511,7 +482,7 @@ static int launch_pass(qsim_state *s, const Pass &p) {
         break;
     }
     case QSIM_K_TILE: {
-        const size_t need = p.ops.size();
+        const size_t need = p.blocks.size();
         if (need > s->ops_cap) return fail(QSIM_ERR_ARG, "tile pass with %zu ops exceeds the op buffer", need);
         if (s->ops_used + need > s->ops_cap) { // ring is full: wait until earlier passes have read their ops
             HIP_TRY(hipStreamSynchronize(s->stream));
@@ -519,14 +490,15 @@ static int launch_pass(qsim_state *s, const Pass &p) {
         }
         TileOp *h = s->h_ops + s->ops_used;
         for (size_t k = 0; k < need; k++)
-            if (!to_tile_op(p.geom, p.ops[k], h[k], s->f32 ? 3 : 4)) return fail(QSIM_ERR_ARG, "internal: block does not fit its tile pass");
-        if (s->f32) // the fp32 kernels read float coefficients from the front of re[] / im[] (rounded once, here)
-            for (size_t k = 0; k < need; k++) {
-                float fr[32], fi[32];
-                for (int e = 0; e < 32; e++) { fr[e] = (float)h[k].re[e]; fi[e] = (float)h[k].im[e]; }
-                memcpy(h[k].re, fr, sizeof fr);
-                memcpy(h[k].im, fi, sizeof fi);
-            }
+            if (!to_tile_op(p.geom, p.blocks[k], h[k], s->f32 ? 3 : 4)) return fail(QSIM_ERR_ARG, "internal: block does not fit its tile pass");
+        if (s->f32) // the fp32 kernels read float coefficients from the front of each bank's re[] / im[] (rounded once, here)
+            for (size_t k = 0; k < need; k++)
+                for (int v = 0; v < kMaxBanks; v++) {
+                    float fr[32], fi[32];
+                    for (int e = 0; e < 32; e++) { fr[e] = (float)h[k].re[v][e]; fi[e] = (float)h[k].im[v][e]; }
+                    memcpy(h[k].re[v], fr, sizeof fr);
+                    memcpy(h[k].im[v], fi, sizeof fi);
+                }
         TileOp *d = s->d_ops + s->ops_used;
         HIP_TRY(hipMemcpyAsync(d, h, need * sizeof(TileOp), hipMemcpyHostToDevice, s->stream));
         s->ops_used += need;
@@ -837,19 +809,29 @@ extern "C" int qsim_schedule_circuit(const qsim_circuit *c, int fuse, int tile_b
     std::vector<Pass> passes;
     sched.finish(passes);
     int pi = 0;
+    std::vector<double> big((size_t)2 * 32 * 32);
+    std::vector<cd> full((size_t)32 * 32);
     for (const Pass &p : passes) {
         for (const FusedOp &op : p.ops) {
             double U[128];
             const int d = op.kind == OP_CX ? 0 : op.dim();
             for (int k = 0; k < d * d; k++) { U[2 * k] = op.m[k].real(); U[2 * k + 1] = op.m[k].imag(); }
-            if (p.kclass == QSIM_K_TILE) { // every block must lie inside the tile the pass declares and be expressible
-                TileOp t;
-                if (!to_tile_op(p.geom, op, t)) return fail(QSIM_ERR_ARG, "internal: block does not fit its tile pass");
-            }
             const int kind = op.kind == OP_G1 ? QSIM_GATE_U1 : op.kind == OP_CX ? QSIM_GATE_CX
                              : op.kind == OP_G2 ? QSIM_GATE_U2 : QSIM_GATE_U3;
             const int qs[3] = {op.q_hi, op.q_lo, op.q_lo2};
             cb(user, pi, p.kclass, kind, qs, op.kind == OP_CX ? 2 : op.nq(), d ? U : nullptr, (int)op.gates);
+        }
+        for (const TileBlock &blk : p.blocks) { // reported as ONE matrix on (selecting qubits..., tile qubits...)
+            TileOp t;
+            if (!to_tile_op(p.geom, blk, t)) return fail(QSIM_ERR_ARG, "internal: block does not fit its tile pass");
+            const int nq = blk.ns + blk.nq, D = 1 << nq;
+            blk.full_matrix(full.data());
+            for (int k = 0; k < D * D; k++) { big[2 * k] = full[k].real(); big[2 * k + 1] = full[k].imag(); }
+            int qs[5], j = 0;
+            for (int a = 0; a < blk.ns; a++) qs[j++] = blk.s[a];
+            for (int a = 0; a < blk.nq; a++) qs[j++] = blk.q[a];
+            static const int kinds[6] = {0, QSIM_GATE_U1, QSIM_GATE_U2, QSIM_GATE_U3, QSIM_GATE_U4, QSIM_GATE_U5};
+            cb(user, pi, p.kclass, kinds[nq], qs, nq, big.data(), (int)blk.gates);
         }
         pi++;
     }

@@ -16,34 +16,42 @@ struct M4 { double re[16], im[16]; };
 
 // One fused block inside a cache-blocked pass.  Bit positions are TILE-LOCAL (see TileGeom), ascending:
 // b[0] is the block's lowest qubit = bit 0 of a slot code, b[k-1] its highest = the slot code's top bit.
-//   TOP_G1     dense 2x2 on b[0]                      re/im[0..3] row-major
-//   TOP_DIAG1  diag(d0, d1) on b[0]                   re/im[0..1]; meta bit 0: d0 == 1 (only the bit=1 half moves)
-//   TOP_G2     dense 4x4 on (b[1], b[0])              re/im[0..15] row-major, operands held in registers
+//   TOP_G1     dense 2x2 on b[0]                      re/im[bank][0..3] row-major
+//   TOP_DIAG1  diag(d0, d1) on b[0]                   re/im[bank][0..1]; meta[bank] bit 0: d0 == 1 (only the bit=1 half moves)
+//   TOP_G2     dense 4x4 on (b[1], b[0])              re/im[bank][0..15] row-major, operands held in registers
 //   TOP_SP     sparse 2^k x 2^k block, k = nq in {2,3}: every row r has `terms` (1, 2 or 4) entries
 //              y[r] = sum_j coef[r*terms + j] * x[slot_j], operands fetched straight from their LDS slots: the host
-//              stores each entry's slot as a ready LDS index offset (wave-uniform), rows with meta bit r set are
+//              stores each entry's slot as a ready LDS byte offset (wave-uniform), rows with meta[bank] bit r set are
 //              untouched (identity row) and cost nothing.  (A per-entry "coefficient is exactly 1" shortcut was
 //              measured and dropped: its wave-uniform branches serialise the LDS reads and double the scalar
 //              instruction count.)
 //              Most fused clusters of Clifford+T-like circuits are permutations times phases or two independent
-//              2x2 blocks, and so are products of neighbouring ones on <= 3 qubits (Scheduler::merge_sparse).
+//              2x2 blocks, and so are products of neighbouring ones on <= 3 qubits (Scheduler::merge_blocks).
+//   TOP_SCALE  no qubit inside the tile: a factor per tile, applied while the tile is staged in.
+// BANKS.  A block may also depend on up to two qubits OUTSIDE the tile, provided it is block-diagonal in them (a CX
+// whose control is outside, any diagonal gate): such a qubit is constant over a tile, so it merely selects which
+// 2^k x 2^k sub-block the tile gets.  nsel / selbit name those GLOBAL index bits; the bank index is
+// bit(selbit[0]) or 2*bit(selbit[0]) + bit(selbit[1]) of the tile's base index, wave-uniform, and only that bank's
+// offsets and coefficients are ever loaded.  `ident` bit v: bank v is the identity — the block is skipped on those tiles.
+// TOP_SCALE uses the same selection and reads its factor from re/im[bank][0].
 enum : int32_t { TOP_G1 = 1, TOP_G2 = 2, TOP_DIAG1 = 3, TOP_SP = 4, TOP_SCALE = 5 };
+constexpr int kMaxBanks = 4;
 struct TileOp {
     int32_t kind;
-    int32_t nq;       // qubits of the block (1..3)
-    int32_t b[3];     // tile-local bits, ascending
-    int32_t terms;    // TOP_SP: entries per row (1, 2, 4)
-    int32_t meta;     // see above; selected TOP_G1: bit v set = bank v is the identity (the block is skipped on those tiles)
-    uint32_t sel;     // TOP_G1: 0, or 1 + the GLOBAL index bit (outside the tile) that selects the coefficient bank:
-                      // re/im[0..3] where that bit of the tile's base index is 0, re/im[4..7] where it is 1.
-                      // TOP_SCALE (tile-uniform factor, applied while the tile is staged in): b[0] (and b[1], or -1) are
-                      // GLOBAL index bits outside the tile; the factor is re/im[bit(b[0])] or re/im[2*bit(b[0]) + bit(b[1])]
-    uint32_t off[32];    // TOP_SP: LDS BYTE offset of entry e's operand slot
-    uint32_t rowoff[8];  // TOP_SP: LDS BYTE offset of row r's slot
-    double re[32];
-    double im[32];
+    int32_t nq;        // qubits of the block inside the tile (0..3)
+    int32_t b[3];      // tile-local bits, ascending
+    int32_t terms;     // TOP_SP: entries per row (1, 2, 4), the same for every bank
+    int32_t nsel;      // 0..2 selecting qubits
+    int32_t selbit[2]; // their global index bits, most significant bank bit first
+    int32_t ident;
+    int32_t meta[kMaxBanks];
+    int32_t pad[2];
+    uint32_t rowoff[8];           // TOP_SP: LDS BYTE offset of row r's slot
+    uint32_t off[kMaxBanks][32];  // TOP_SP: LDS BYTE offset of entry e's operand slot
+    double re[kMaxBanks][32];
+    double im[kMaxBanks][32];
 };
-static_assert(sizeof(TileOp) == 704, "TileOp layout is shared with the device");
+static_assert(sizeof(TileOp) == 64 + 32 + 512 + 2048, "TileOp layout is shared with the device");
 
 constexpr int kMaxTileHigh = 10; // high (non-contiguous) qubits per tile
 struct TileGeom {

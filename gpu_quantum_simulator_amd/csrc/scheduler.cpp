@@ -128,7 +128,7 @@ void Scheduler::add_1q(const cd U[4], int q) {
     }
     // Level 3 keeps a pair cluster block-diagonal in a qubit for as long as it can: such a cluster can run in passes
     // whose tile does not contain that qubit.  A gate that would mix the qubit's halves starts a new cluster instead
-    // (inside one pass the two are merged again by merge_sparse).
+    // (inside one pass the two are merged again by merge_blocks).
     if (cfg_.fuse >= 3 && cfg_.selectors && pool_[idx].kind == OP_G2 && (!is_zero(U[1]) || !is_zero(U[2])) &&
         (pool_[idx].selector_mask() >> q & 1ULL)) {
         close(idx);
@@ -225,6 +225,67 @@ void Scheduler::finish(std::vector<Pass> &out) {
     finish([&out](Pass &&p) { out.push_back(std::move(p)); });
 }
 
+// ---- tile blocks ----------------------------------------------------------------------------------------
+int TileBlock::max_row_nnz() const {
+    const int d = dim();
+    int best = 0;
+    for (int v = 0; v < banks(); v++)
+        for (int r = 0; r < d; r++) {
+            int cnt = 0;
+            for (int c = 0; c < d; c++) cnt += !is_zero(bank[v][d * r + c]);
+            best = std::max(best, cnt);
+        }
+    return best;
+}
+
+bool TileBlock::bank_is_identity(int v) const {
+    const int d = dim();
+    for (int r = 0; r < d; r++)
+        for (int c = 0; c < d; c++)
+            if (r == c ? !is_one(bank[v][d * r + c]) : !is_zero(bank[v][d * r + c])) return false;
+    return true;
+}
+
+bool TileBlock::is_identity() const {
+    for (int v = 0; v < banks(); v++)
+        if (!bank_is_identity(v)) return false;
+    return true;
+}
+
+void TileBlock::full_matrix(cd *out) const {
+    const int d = dim(), D = d << ns;
+    std::fill(out, out + (size_t)D * D, cd(0, 0));
+    for (int v = 0; v < banks(); v++)
+        for (int r = 0; r < d; r++)
+            for (int c = 0; c < d; c++) out[(size_t)(v * d + r) * D + (v * d + c)] = bank[v][d * r + c];
+}
+
+// Splits a fused op (1 or 2 qubits at level 3) by the tile: qubits in `inside` stay matrix indices, the others become
+// bank selectors.  The op must be block-diagonal in every qubit left outside.
+static TileBlock to_block(const FusedOp &op, uint64_t inside) {
+    TileBlock t;
+    t.gates = op.gates;
+    const int k = op.nq(), D = op.dim();
+    const int qs[3] = {op.q_hi, op.q_lo, op.q_lo2};
+    int in_pos[3], sel_pos[3]; // bit positions (in the op's row index) of the inside / outside qubits, most significant first
+    for (int a = 0; a < k; a++) {
+        const int pos = k - 1 - a;
+        if (inside >> qs[a] & 1ULL) { in_pos[t.nq] = pos; t.q[t.nq++] = qs[a]; }
+        else { sel_pos[t.ns] = pos; t.s[t.ns++] = qs[a]; }
+    }
+    const int d = 1 << t.nq;
+    auto compose = [&](int v, int r) { // op row index from bank index v and inside row index r
+        int idx = 0;
+        for (int a = 0; a < t.ns; a++) idx |= ((v >> (t.ns - 1 - a)) & 1) << sel_pos[a];
+        for (int a = 0; a < t.nq; a++) idx |= ((r >> (t.nq - 1 - a)) & 1) << in_pos[a];
+        return idx;
+    };
+    for (int v = 0; v < (1 << t.ns); v++)
+        for (int r = 0; r < d; r++)
+            for (int c = 0; c < d; c++) t.bank[v][d * r + c] = op.m[D * compose(v, r) + compose(v, c)];
+    return t;
+}
+
 // ---- pass construction --------------------------------------------------------------------------------
 void Scheduler::single_op_pass(const FusedOp &op, const PassSink &sink) const {
     const double S = 16.0 * (double)(1ULL << cfg_.n); // bytes of state
@@ -296,30 +357,31 @@ void Scheduler::tile_pass(const std::vector<FusedOp> &ops, uint64_t hset, const 
     for (int b = L; b < cfg_.n; b++)
         if (high >> b & 1ULL) p.geom.high[p.geom.n_high++] = b;
 
-    // Blocks with every qubit outside the tile are tile-uniform factors: they commute with everything else in the pass
-    // (nothing in it can touch those qubits except other blocks that are block-diagonal in them) and go to the front,
-    // one entry per qubit set.
+    // Every block is split into the qubits it has inside the tile and the ones outside (it is block-diagonal in those:
+    // build_passes only leaves such qubits out).  Blocks with nothing inside are tile-uniform factors: they commute
+    // with everything else in the pass and go to the front, one entry per qubit set.
     const uint64_t inside = lowmask | high;
-    std::vector<FusedOp> scalars, blocks;
-    for (FusedOp op : ops) {
-        op.sel_mask = op.qmask() & ~inside;
-        if (!op.is_scalar_in_tile()) { blocks.push_back(op); continue; }
+    std::vector<TileBlock> scalars, blocks;
+    for (const FusedOp &op : ops) {
+        TileBlock tb = to_block(op, inside);
+        if (tb.nq > 0) { blocks.push_back(tb); continue; }
         bool folded = false;
-        for (FusedOp &sc : scalars)
-            if (sc.kind == op.kind && sc.q_hi == op.q_hi && sc.q_lo == op.q_lo) {
-                const int d = op.dim();
-                for (int r = 0; r < d; r++) sc.m[(d + 1) * r] = op.m[(d + 1) * r] * sc.m[(d + 1) * r];
-                sc.gates += op.gates;
+        for (TileBlock &sc : scalars)
+            if (sc.ns == tb.ns && sc.s[0] == tb.s[0] && sc.s[1] == tb.s[1]) {
+                for (int v = 0; v < tb.banks(); v++) sc.bank[v][0] = tb.bank[v][0] * sc.bank[v][0];
+                sc.gates += tb.gates;
                 folded = true;
                 break;
             }
-        if (!folded) scalars.push_back(op);
+        if (!folded) scalars.push_back(tb);
     }
-    if (cfg_.merge && blocks.size() > 1) merge_sparse(blocks);
+    if (cfg_.merge && blocks.size() > 1) merge_blocks(blocks);
+    else blocks.erase(std::remove_if(blocks.begin(), blocks.end(), [](const TileBlock &t) { return t.is_identity(); }), blocks.end());
+    scalars.erase(std::remove_if(scalars.begin(), scalars.end(), [](const TileBlock &t) { return t.is_identity(); }), scalars.end());
     p.geom.n_scale = (int)scalars.size();
-    p.ops = std::move(scalars);
-    p.ops.insert(p.ops.end(), blocks.begin(), blocks.end());
-    if (p.ops.empty()) return;
+    p.blocks = std::move(scalars);
+    p.blocks.insert(p.blocks.end(), blocks.begin(), blocks.end());
+    if (p.blocks.empty()) return;
     sink(std::move(p));
 }
 
@@ -421,75 +483,77 @@ void Scheduler::build_passes(const PassSink &sink) {
 
 // ---- sparse merging inside a pass -------------------------------------------------------------------------
 // Most fused clusters are permutations-times-phases or two independent 2x2 blocks (exact zeros), so the product
-// of neighbours on <= 3 qubits usually still has <= 4 entries per row.  Such a product costs ONE trip through
+// of neighbours on <= 3 tile qubits usually still has <= 4 entries per row.  Such a product costs ONE trip through
 // LDS in k_tile instead of one per factor, which is what bounds a pass once it carries more than ~6 blocks.
-// Order: a block may hop over earlier blocks it shares no qubit with (they commute); everything it shares a
-// qubit with and cannot join blocks those qubits for the rest of the scan.
+// Order: a block may hop over earlier blocks it shares no TILE qubit with (they commute: outside the tile every block
+// of the pass is block-diagonal); everything it shares a tile qubit with and cannot join blocks those qubits for the
+// rest of the scan.  Selecting qubits are merged too: the product has one bank per value of the union (at most two).
 namespace {
 
-// embeds `op` (on its own qubits) into the space of qubits `qs` (descending), writing a (1<<k) x (1<<k) matrix
-void embed(const FusedOp &op, const int *qs, int k, cd *out) {
-    const int D = 1 << k, d = op.dim();
-    int opq[3] = {op.q_hi, op.q_lo, op.q_lo2};
-    int pos[3] = {0, 0, 0}; // bit position (inside the k-bit index) of each op qubit
-    for (int a = 0; a < op.nq(); a++)
-        for (int b = 0; b < k; b++)
-            if (qs[b] == opq[a]) pos[a] = k - 1 - b;
+// embeds bank `v` (given over the selector list ss[0..nss)) of `b` into the space of tile qubits qs[0..k) (descending)
+void embed_bank(const TileBlock &b, const int *qs, int k, const int *ss, int nss, int v, cd *out) {
+    int bv = 0; // the block's own bank index under the joint selector value v
+    for (int a = 0; a < b.ns; a++)
+        for (int j = 0; j < nss; j++)
+            if (ss[j] == b.s[a]) bv |= ((v >> (nss - 1 - j)) & 1) << (b.ns - 1 - a);
+    const int D = 1 << k, d = b.dim();
+    int pos[3] = {0, 0, 0}; // bit position (inside the k-bit index) of each of the block's qubits
+    for (int a = 0; a < b.nq; a++)
+        for (int j = 0; j < k; j++)
+            if (qs[j] == b.q[a]) pos[a] = k - 1 - j;
     int opmask = 0;
-    for (int a = 0; a < op.nq(); a++) opmask |= 1 << pos[a];
-    auto sub = [&](int idx) { // index of `idx` restricted to the op's qubits, most significant first
-        int v = 0;
-        for (int a = 0; a < op.nq(); a++) v = (v << 1) | ((idx >> pos[a]) & 1);
-        return v;
+    for (int a = 0; a < b.nq; a++) opmask |= 1 << pos[a];
+    auto sub = [&](int idx) {
+        int r = 0;
+        for (int a = 0; a < b.nq; a++) r = (r << 1) | ((idx >> pos[a]) & 1);
+        return r;
     };
     for (int r = 0; r < D; r++)
         for (int c = 0; c < D; c++)
-            out[D * r + c] = ((r & ~opmask) == (c & ~opmask)) ? op.m[d * sub(r) + sub(c)] : cd(0, 0);
+            out[D * r + c] = ((r & ~opmask) == (c & ~opmask)) ? b.bank[bv][d * sub(r) + sub(c)] : cd(0, 0);
 }
 
 } // namespace
 
-void Scheduler::merge_sparse(std::vector<FusedOp> &ops) const {
-    constexpr int kMaxQ = 3, kMaxNnz = 4;
-    std::vector<FusedOp> rem(ops), next, out;
+void Scheduler::merge_blocks(std::vector<TileBlock> &blocks) const {
+    constexpr int kMaxQ = 3, kMaxNnz = 4, kMaxSel = 2;
+    std::vector<TileBlock> rem(blocks), next, out;
     while (!rem.empty()) {
-        FusedOp cur = rem[0];
-        if (cur.sel_mask) { // a block selected by out-of-tile bits is emitted as it is
-            out.push_back(cur);
-            rem.erase(rem.begin());
-            continue;
-        }
+        TileBlock cur = rem[0];
         uint64_t blocked = 0;
         next.clear();
         for (size_t i = 1; i < rem.size(); i++) {
-            const FusedOp &op = rem[i];
-            const uint64_t qm = op.qmask() & ~op.sel_mask; // what it touches inside the tile
+            const TileBlock &op = rem[i];
+            const uint64_t qm = op.in_mask();
             if (qm & blocked) { blocked |= qm; next.push_back(op); continue; }
-            const uint64_t un = cur.qmask() | qm;
+            const uint64_t un = cur.in_mask() | qm, us = cur.sel_mask() | op.sel_mask();
             bool merged = false;
-            if (!op.sel_mask && __builtin_popcountll(un) <= kMaxQ && cur.kind != OP_CX && op.kind != OP_CX &&
+            if (__builtin_popcountll(un) <= kMaxQ && __builtin_popcountll(us) <= kMaxSel &&
                 cur.max_row_nnz() * op.max_row_nnz() <= 2 * kMaxNnz) {
-                int qs[3], k = 0;
-                for (int b = 63; b >= 0; b--)
+                int qs[3], k = 0, ss[2], nss = 0;
+                for (int b = 63; b >= 0; b--) {
                     if (un >> b & 1ULL) qs[k++] = b;
+                    if (us >> b & 1ULL) ss[nss++] = b;
+                }
                 const int D = 1 << k;
-                cd a[64], b2[64], prod[64];
-                embed(cur, qs, k, a);
-                embed(op, qs, k, b2);
-                for (int r = 0; r < D; r++)
-                    for (int c = 0; c < D; c++) {
-                        cd acc(0, 0);
-                        for (int t = 0; t < D; t++)
-                            if (!is_zero(b2[D * r + t]) && !is_zero(a[D * t + c])) acc += b2[D * r + t] * a[D * t + c];
-                        prod[D * r + c] = acc;
-                    }
-                FusedOp m;
-                m.kind = k == 1 ? OP_G1 : k == 2 ? OP_G2 : OP_G3;
-                m.q_hi = qs[0];
-                m.q_lo = k > 1 ? qs[1] : -1;
-                m.q_lo2 = k > 2 ? qs[2] : -1;
-                std::copy(prod, prod + D * D, m.m);
+                TileBlock m;
+                m.nq = k;
+                m.ns = nss;
+                for (int a = 0; a < k; a++) m.q[a] = qs[a];
+                for (int a = 0; a < nss; a++) m.s[a] = ss[a];
                 m.gates = cur.gates + op.gates;
+                for (int v = 0; v < (1 << nss); v++) {
+                    cd a[64], b2[64];
+                    embed_bank(cur, qs, k, ss, nss, v, a);
+                    embed_bank(op, qs, k, ss, nss, v, b2);
+                    for (int r = 0; r < D; r++)
+                        for (int c = 0; c < D; c++) {
+                            cd acc(0, 0);
+                            for (int t = 0; t < D; t++)
+                                if (!is_zero(b2[D * r + t]) && !is_zero(a[D * t + c])) acc += b2[D * r + t] * a[D * t + c];
+                            m.bank[v][D * r + c] = acc;
+                        }
+                }
                 // a 3-qubit product is only worth it while it stays sparse; 1- and 2-qubit products always fold
                 if (k <= 2 || m.max_row_nnz() <= kMaxNnz) {
                     cur = m;
@@ -501,7 +565,7 @@ void Scheduler::merge_sparse(std::vector<FusedOp> &ops) const {
         if (!cur.is_identity()) out.push_back(cur);
         rem.swap(next);
     }
-    ops.swap(out);
+    blocks.swap(out);
 }
 
 } // namespace qsim

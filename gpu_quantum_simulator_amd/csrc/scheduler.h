@@ -30,10 +30,6 @@ struct FusedOp {
     int q_lo2 = -1; // OP_G3: lowest qubit
     cd m[64];       // row-major 2x2 / 4x4 / 8x8; index bits = (q_hi, q_lo[, q_lo2]), most significant first
     uint32_t gates = 0;
-    // Set when the op is emitted into a tile pass: those of its qubits that are NOT in the pass's tile.  The op is
-    // block-diagonal in each of them (selector_mask), so per tile it reduces to the sub-block picked by those bits of
-    // the tile's base index: a smaller block on the in-tile qubits, or a plain factor when none is left.
-    uint64_t sel_mask = 0;
 
     int nq() const { return kind == OP_G1 ? 1 : kind == OP_G3 ? 3 : 2; }
     int dim() const { return 1 << nq(); }
@@ -47,13 +43,42 @@ struct FusedOp {
     bool is_diag() const;
     bool is_identity() const;
     uint64_t selector_mask() const; // qubits the matrix is block-diagonal in (exact zeros): it never mixes their 0 and 1 halves
-    bool is_scalar_in_tile() const { return sel_mask != 0 && sel_mask == qmask(); }
+};
+
+// One block of a tile pass = one trip through LDS.  `q` are its qubits inside the tile; `s` are qubits OUTSIDE the tile
+// that the block is block-diagonal in: constant over a tile, they only select which bank (sub-block on `q`) applies.
+// nq == 0: a tile-uniform factor (bank[v][0]).
+struct TileBlock {
+    int nq = 0;
+    int q[3] = {-1, -1, -1}; // descending: q[0] is the most significant bit of the row/column index
+    int ns = 0;
+    int s[2] = {-1, -1};     // descending: s[0] is the most significant bit of the bank index
+    cd bank[kMaxBanks][64];  // row-major (1 << nq) x (1 << nq)
+    uint32_t gates = 0;
+
+    int dim() const { return 1 << nq; }
+    int banks() const { return 1 << ns; }
+    uint64_t in_mask() const { uint64_t m = 0; for (int a = 0; a < nq; a++) m |= 1ULL << q[a]; return m; }
+    uint64_t sel_mask() const { uint64_t m = 0; for (int a = 0; a < ns; a++) m |= 1ULL << s[a]; return m; }
+    int max_row_nnz() const;    // over all banks
+    bool bank_is_identity(int v) const;
+    bool is_identity() const;   // every bank
+    // the block as ONE matrix on the qubits (s..., q...), most significant first: block-diagonal in the bank index.
+    // `out` holds (1 << (ns + nq))^2 entries.
+    void full_matrix(cd *out) const;
 };
 
 struct Pass {
     int kclass = 0;           // QSIM_K_*
-    std::vector<FusedOp> ops; // one op unless kclass == QSIM_K_TILE
-    TileGeom geom{};          // QSIM_K_TILE only
+    std::vector<FusedOp> ops;      // the one op of a single-op pass; empty for QSIM_K_TILE
+    std::vector<TileBlock> blocks; // QSIM_K_TILE: geom.n_scale tile-uniform factors first, then the blocks in order
+    TileGeom geom{};               // QSIM_K_TILE only
+    uint32_t gates() const {
+        uint32_t g = 0;
+        for (const FusedOp &op : ops) g += op.gates;
+        for (const TileBlock &b : blocks) g += b.gates;
+        return g;
+    }
     double bytes = 0;         // algorithmic bytes this pass must move
     bool diag_full = false;   // QSIM_K_PHASE executed over every amplitude (d0 != 1 or q < 2)
 };
@@ -68,7 +93,7 @@ struct SchedConfig {
     int merge = 1;     // level 3: merge neighbouring blocks of a pass into sparse <=3-qubit blocks
     int rollout = 8;   // level 3: candidates tried (each by greedily finishing the pass) when a new qubit must be admitted; 0 = off
     int pad_from = 10; // first bit tried when unused tile slots are filled (below tile_low_bits: tile_low_bits)
-    int selectors = 0; // level 3: a block may run in a pass whose tile lacks qubits it is block-diagonal in
+    int selectors = 1; // level 3: a block may run in a pass whose tile lacks qubits it is block-diagonal in
 };
 
 class Scheduler {
@@ -103,7 +128,7 @@ class Scheduler {
     void build_passes(const PassSink &sink);
     void single_op_pass(const FusedOp &op, const PassSink &sink) const;
     void tile_pass(const std::vector<FusedOp> &ops, uint64_t hset, const PassSink &sink) const;
-    void merge_sparse(std::vector<FusedOp> &ops) const;
+    void merge_blocks(std::vector<TileBlock> &blocks) const;
 };
 
 } // namespace qsim

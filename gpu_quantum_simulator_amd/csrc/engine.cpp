@@ -345,6 +345,10 @@ static SchedConfig sched_config(int n, int fuse, int tile_bits, int tile_low_bit
     SchedConfig c;
     c.pad_from = pad_from;
     c.n = n; c.fuse = fuse; c.tile_bits = tile_bits; c.tile_low_bits = tile_low_bits; c.tile_max_ops = tile_max_ops;
+    // The pass-set local search (SchedConfig::local_iters / lookahead; ~1.4 ms of host time per pass, hidden behind the
+    // GPU for n >= 28) brings the n = 30 bench circuit from 17 to 15 passes, but the passes it builds carry more blocks
+    // and run LDS-bound (8.9 instead of 7.8 ms each): the same 133 ms in total today, so it stays off.  QSIM_SCHED_LOCAL /
+    // QSIM_SCHED_LOOKAHEAD in the environment turn it on for experiments.
     return c;
 }
 

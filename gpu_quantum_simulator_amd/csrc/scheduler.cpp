@@ -3,6 +3,7 @@
 #include "scheduler.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace qsim {
@@ -97,7 +98,14 @@ void Scheduler::cx4(bool control_is_hi, cd out[16]) {
 // built on the host, so that is irrelevant.  Zeros stay exact: every term of an off-diagonal entry of a
 // product of diagonal matrices has an exact-zero factor.
 
-Scheduler::Scheduler(const SchedConfig &cfg) : cfg_(cfg), open_(cfg.n > 0 ? cfg.n : 0, -1) {}
+Scheduler::Scheduler(const SchedConfig &cfg) : cfg_(cfg), open_(cfg.n > 0 ? cfg.n : 0, -1) {
+    if (const char *v = getenv("QSIM_SCHED_LOOKAHEAD")) cfg_.lookahead = atoi(v);
+    if (const char *v = getenv("QSIM_SCHED_ROLLOUT")) cfg_.rollout = atoi(v);
+    if (const char *v = getenv("QSIM_SCHED_WINDOW")) cfg_.window = atoi(v);
+    if (const char *v = getenv("QSIM_SCHED_LOCAL")) cfg_.local_iters = atoi(v);
+    if (const char *v = getenv("QSIM_SCHED_OBJ")) cfg_.objective = atoi(v);
+    if (const char *v = getenv("QSIM_SCHED_MERGE")) cfg_.merge = atoi(v);
+}
 
 void Scheduler::close(int idx) {
     if (idx < 0) return;
@@ -440,7 +448,51 @@ void Scheduler::build_passes(const PassSink &sink) {
             hset |= must[(size_t)c.idx] & ~lowmask;
             cnt++;
         }
+        // look further: what the following passes reach when each is simply built greedily
+        for (int extra = 0; extra < cfg_.lookahead; extra++) {
+            uint64_t h2 = 0;
+            int c2 = 0;
+            while (c2 < cfg_.tile_max_ops) {
+                const Cand c = scan(dn, from, to, h2, nullptr);
+                if (c.idx < 0) break;
+                dn[(size_t)c.idx] = 1;
+                h2 |= must[(size_t)c.idx] & ~lowmask;
+                c2++;
+            }
+            cnt += c2;
+        }
         return cnt;
+    };
+
+    // Blocks a pass with high-qubit set S executes, in index order (a valid execution order: a block runs only if
+    // every earlier pending block on its qubits ran), and their score.
+    std::vector<long> picks, best_picks;
+    auto eval = [&](const std::vector<char> &dn, size_t from, size_t to, uint64_t S, std::vector<long> *out) {
+        uint64_t blocked = 0;
+        int score = 0, cnt = 0;
+        if (out) out->clear();
+        for (size_t i = from; i < to && cnt < cfg_.tile_max_ops; i++) {
+            if (dn[i]) continue;
+            if (!(qm[i] & blocked) && !(must[i] & ~lowmask & ~S)) {
+                score += cfg_.objective ? (int)closed_[i].gates : 1;
+                cnt++;
+                if (out) out->push_back((long)i);
+            } else {
+                blocked |= qm[i];
+                if (blocked == all) break;
+            }
+        }
+        return score;
+    };
+    auto eval_ahead = [&](size_t from, size_t to, uint64_t S, std::vector<long> *out) {
+        int score = eval(done, from, to, S, out ? out : &picks);
+        if (cfg_.lookahead > 0) {
+            trial = done;
+            for (long i : (out ? *out : picks)) trial[(size_t)i] = 1;
+            std::vector<char> t2 = trial;
+            score += rollout(t2, from, to, 0, 0) ; // the next pass, built greedily (plus cfg_.lookahead - 1 more inside)
+        }
+        return score;
     };
 
     std::vector<Cand> cands;
@@ -449,9 +501,12 @@ void Scheduler::build_passes(const PassSink &sink) {
         group.clear();
         uint64_t hset = 0;
         const size_t end = std::min(m, first + (size_t)cfg_.window);
-        while ((int)group.size() < cfg_.tile_max_ops) {
+        // 1. greedy construction on a copy: cheapest new qubit first, ties broken by a rollout
+        std::vector<char> work = done;
+        int have = 0;
+        while (have < cfg_.tile_max_ops) {
             cands.clear();
-            Cand pick = scan(done, first, end, hset, cfg_.rollout > 1 ? &cands : nullptr);
+            Cand pick = scan(work, first, end, hset, cfg_.rollout > 1 ? &cands : nullptr);
             if (pick.idx < 0) break;
             if (pick.need > 0 && cfg_.rollout > 1 && cands.size() > 1) {
                 // a new qubit has to be admitted: try the cheapest few candidates and keep the one after which a
@@ -460,15 +515,44 @@ void Scheduler::build_passes(const PassSink &sink) {
                 int best_score = -1;
                 const size_t tries = std::min(cands.size(), (size_t)cfg_.rollout);
                 for (size_t t = 0; t < tries; t++) {
-                    trial = done;
+                    trial = work;
                     trial[(size_t)cands[t].idx] = 1;
-                    const int score = rollout(trial, first, end, hset | (must[(size_t)cands[t].idx] & ~lowmask), (int)group.size() + 1);
+                    const int score = rollout(trial, first, end, hset | (must[(size_t)cands[t].idx] & ~lowmask), have + 1);
                     if (score > best_score) { best_score = score; pick = cands[t]; }
                 }
             }
-            group.push_back(closed_[(size_t)pick.idx]);
             hset |= must[(size_t)pick.idx] & ~lowmask;
-            done[(size_t)pick.idx] = 1;
+            work[(size_t)pick.idx] = 1;
+            have++;
+        }
+        // 2. local search over the qubit set: swap one chosen high qubit for one left out while the pass (and, with
+        //    lookahead, the greedy passes after it) executes more.  The host has milliseconds per pass to spend here:
+        //    the GPU is busy with the previous pass for ~7 ms at n = 30.
+        if (cfg_.local_iters > 0 && __builtin_popcountll(hset) >= 2) {
+            int best = eval_ahead(first, end, hset, &best_picks);
+            for (int it = 0; it < cfg_.local_iters; it++) {
+                uint64_t bestS = hset;
+                for (uint64_t in = hset; in; in &= in - 1) {
+                    const uint64_t qi = in & (0 - in);
+                    for (int b = L; b < cfg_.n; b++) {
+                        if (hset >> b & 1ULL) continue;
+                        const uint64_t S2 = (hset & ~qi) | (1ULL << b);
+                        const int v = eval_ahead(first, end, S2, nullptr);
+                        if (v > best) { best = v; bestS = S2; }
+                    }
+                }
+                if (bestS == hset) break;
+                hset = bestS;
+            }
+        }
+        eval(done, first, end, hset, &best_picks);
+        if (best_picks.empty()) { // the set cannot be worse than the greedy one; keep the scheduler total anyway
+            best_picks.push_back((long)first);
+            hset = must[first] & ~lowmask;
+        }
+        for (long i : best_picks) {
+            group.push_back(closed_[(size_t)i]);
+            done[(size_t)i] = 1;
         }
         if (group.empty()) { // cannot happen while kmax >= 2; keep the scheduler total anyway
             single_op_pass(closed_[first], sink);

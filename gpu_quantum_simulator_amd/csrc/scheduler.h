@@ -93,6 +93,9 @@ struct SchedConfig {
     int merge = 1;     // level 3: merge neighbouring blocks of a pass into sparse <=3-qubit blocks
     int rollout = 8;   // level 3: candidates tried (each by greedily finishing the pass) when a new qubit must be admitted; 0 = off
     int pad_from = 10; // first bit tried when unused tile slots are filled (below tile_low_bits: tile_low_bits)
+    int lookahead = 0; // level 3: further passes (built greedily) whose reach is added to a candidate's score
+    int local_iters = 0; // level 3: rounds of swap-one-qubit local search on each pass's qubit set
+    int objective = 0; // what a pass maximises: 0 blocks, 1 source gates
     int selectors = 1; // level 3: a block may run in a pass whose tile lacks qubits it is block-diagonal in
 };
 

@@ -93,7 +93,7 @@ struct qsim_state {
     std::vector<hipEvent_t> event_pool; // reusable
 };
 
-static constexpr size_t kOpsCap = 2048; // a pass holds <= tile_max_ops blocks; the ring wraps with a stream sync
+static constexpr size_t kOpsCap = 512;  // a pass holds <= tile_max_ops blocks; the ring wraps with a stream sync
 
 static int make_state(qsim_state **out, int num_q, int device, void *ext, bool f32 = false) {
     if (!out) return fail(QSIM_ERR_ARG, "qsim_create: out is NULL");
@@ -368,11 +368,11 @@ static inline int local_bit(const TileGeom &g, int q) {
 }
 
 // TileBlock -> device TileOp.  Returns false when a qubit is on the wrong side of the tile or the block cannot be
-// expressed (a 3-qubit block with more than 4 entries per row; Scheduler::merge_blocks never produces one).
+// expressed (Scheduler::merge_blocks never produces such a block).
 static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, int amp_shift = 4) {
     memset(&t, 0, sizeof t);
     const int k = blk.nq, D = blk.dim(), NB = blk.banks();
-    if (k > 3 || blk.ns > 2) return false;
+    if (k > kMaxOpQ || blk.ns > 2) return false;
     t.nq = k;
     t.nsel = blk.ns;
     for (int a = 0; a < blk.ns; a++) {
@@ -384,28 +384,28 @@ static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, int a
         if (lb < 0) return false;
         t.b[a] = lb;
     }
-    auto nz = [&](int v, int r, int c) { const cd &z = blk.bank[v][D * r + c]; return z.real() != 0.0 || z.imag() != 0.0; };
     auto is1 = [&](const cd &z) { return z.real() == 1.0 && z.imag() == 0.0; };
+    auto put = [&](int v, int e, const cd &z) { t.re[v][e] = z.real(); t.im[v][e] = z.imag(); };
     for (int v = 0; v < NB; v++)
         if (blk.bank_is_identity(v)) t.ident |= 1 << v;
     if (k == 0) { // tile-uniform factor
         if (blk.ns == 0) return false;
         t.kind = TOP_SCALE;
-        for (int v = 0; v < NB; v++) { t.re[v][0] = blk.bank[v][0].real(); t.im[v][0] = blk.bank[v][0].imag(); }
+        for (int v = 0; v < NB; v++) put(v, 0, blk.at(v, 0, 0));
         return true;
     }
     const int maxnnz = blk.max_row_nnz();
     if (k == 1) {
         bool diag = true;
-        for (int v = 0; v < NB; v++) diag = diag && !nz(v, 0, 1) && !nz(v, 1, 0);
+        for (int v = 0; v < NB; v++) diag = diag && blk.at(v, 0, 1) == cd(0, 0) && blk.at(v, 1, 0) == cd(0, 0);
         t.kind = diag ? TOP_DIAG1 : TOP_G1;
         for (int v = 0; v < NB; v++) {
             if (diag) {
-                t.re[v][0] = blk.bank[v][0].real(); t.im[v][0] = blk.bank[v][0].imag();
-                t.re[v][1] = blk.bank[v][3].real(); t.im[v][1] = blk.bank[v][3].imag();
-                t.meta[v] = is1(blk.bank[v][0]) ? 1 : 0;
+                put(v, 0, blk.at(v, 0, 0));
+                put(v, 1, blk.at(v, 1, 1));
+                t.meta[v] = is1(blk.at(v, 0, 0)) ? 1 : 0;
             } else {
-                for (int e = 0; e < 4; e++) { t.re[v][e] = blk.bank[v][e].real(); t.im[v][e] = blk.bank[v][e].imag(); }
+                for (int e = 0; e < 4; e++) put(v, e, blk.at(v, e >> 1, e & 1));
             }
         }
         return true;
@@ -413,7 +413,7 @@ static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, int a
     if (k == 2 && maxnnz > 2) { // dense 4x4: register form
         t.kind = TOP_G2;
         for (int v = 0; v < NB; v++)
-            for (int e = 0; e < 16; e++) { t.re[v][e] = blk.bank[v][e].real(); t.im[v][e] = blk.bank[v][e].imag(); }
+            for (int e = 0; e < 16; e++) put(v, e, blk.at(v, e >> 2, e & 3));
         return true;
     }
     if (maxnnz > 4) return false;
@@ -431,15 +431,14 @@ static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, int a
     for (int r = 0; r < D; r++) t.rowoff[r] = slot_off(r) << amp_shift;
     for (int v = 0; v < NB; v++)
         for (int r = 0; r < D; r++) {
+            const TileBlock::Row &row = blk.rows[v][r];
             int j = 0;
-            for (int c = 0; c < D; c++)
-                if (nz(v, r, c)) {
-                    const int e = r * T + j++;
-                    t.off[v][e] = slot_off(c) << amp_shift;
-                    t.re[v][e] = blk.bank[v][D * r + c].real();
-                    t.im[v][e] = blk.bank[v][D * r + c].imag();
-                }
-            if (j == 1 && nz(v, r, r) && is1(blk.bank[v][D * r + r])) t.meta[v] |= 1 << r; // identity row: no traffic at all
+            for (; j < row.n; j++) {
+                const int e = r * T + j;
+                t.off[v][e] = slot_off(row.col[j]) << amp_shift;
+                put(v, e, row.val[j]);
+            }
+            if (row.n == 1 && row.col[0] == r && is1(row.val[0])) t.meta[v] |= 1u << r; // identity row: no traffic at all
             for (; j < T; j++) t.off[v][r * T + j] = slot_off(r) << amp_shift; // pad: zero coefficient on the row's own slot
         }
     return true;
@@ -498,8 +497,8 @@ static int launch_pass(qsim_state *s, const Pass &p) {
         if (s->f32) // the fp32 kernels read float coefficients from the front of each bank's re[] / im[] (rounded once, here)
             for (size_t k = 0; k < need; k++)
                 for (int v = 0; v < kMaxBanks; v++) {
-                    float fr[32], fi[32];
-                    for (int e = 0; e < 32; e++) { fr[e] = (float)h[k].re[v][e]; fi[e] = (float)h[k].im[v][e]; }
+                    float fr[kMaxOpEntries], fi[kMaxOpEntries];
+                    for (int e = 0; e < kMaxOpEntries; e++) { fr[e] = (float)h[k].re[v][e]; fi[e] = (float)h[k].im[v][e]; }
                     memcpy(h[k].re[v], fr, sizeof fr);
                     memcpy(h[k].im[v], fi, sizeof fi);
                 }
@@ -813,8 +812,8 @@ extern "C" int qsim_schedule_circuit(const qsim_circuit *c, int fuse, int tile_b
     std::vector<Pass> passes;
     sched.finish(passes);
     int pi = 0;
-    std::vector<double> big((size_t)2 * 32 * 32);
-    std::vector<cd> full((size_t)32 * 32);
+    std::vector<double> big((size_t)2 * 128 * 128);
+    std::vector<cd> full((size_t)128 * 128);
     for (const Pass &p : passes) {
         for (const FusedOp &op : p.ops) {
             double U[128];
@@ -831,10 +830,10 @@ extern "C" int qsim_schedule_circuit(const qsim_circuit *c, int fuse, int tile_b
             const int nq = blk.ns + blk.nq, D = 1 << nq;
             blk.full_matrix(full.data());
             for (int k = 0; k < D * D; k++) { big[2 * k] = full[k].real(); big[2 * k + 1] = full[k].imag(); }
-            int qs[5], j = 0;
+            int qs[7], j = 0;
             for (int a = 0; a < blk.ns; a++) qs[j++] = blk.s[a];
             for (int a = 0; a < blk.nq; a++) qs[j++] = blk.q[a];
-            static const int kinds[6] = {0, QSIM_GATE_U1, QSIM_GATE_U2, QSIM_GATE_U3, QSIM_GATE_U4, QSIM_GATE_U5};
+            static const int kinds[8] = {0, QSIM_GATE_U1, QSIM_GATE_U2, QSIM_GATE_U3, QSIM_GATE_U4, QSIM_GATE_U5, QSIM_GATE_U6, QSIM_GATE_U7};
             cb(user, pi, p.kclass, kinds[nq], qs, nq, big.data(), (int)blk.gates);
         }
         pi++;

@@ -19,14 +19,17 @@ struct M4 { double re[16], im[16]; };
 //   TOP_G1     dense 2x2 on b[0]                      re/im[bank][0..3] row-major
 //   TOP_DIAG1  diag(d0, d1) on b[0]                   re/im[bank][0..1]; meta[bank] bit 0: d0 == 1 (only the bit=1 half moves)
 //   TOP_G2     dense 4x4 on (b[1], b[0])              re/im[bank][0..15] row-major, operands held in registers
-//   TOP_SP     sparse 2^k x 2^k block, k = nq in {2,3}: every row r has `terms` (1, 2 or 4) entries
+//   TOP_SP     sparse 2^k x 2^k block, k = nq in {2..5}: every row r has `terms` (1, 2 or 4) entries
 //              y[r] = sum_j coef[r*terms + j] * x[slot_j], operands fetched straight from their LDS slots: the host
 //              stores each entry's slot as a ready LDS byte offset (wave-uniform), rows with meta[bank] bit r set are
 //              untouched (identity row) and cost nothing.  (A per-entry "coefficient is exactly 1" shortcut was
 //              measured and dropped: its wave-uniform branches serialise the LDS reads and double the scalar
 //              instruction count.)
 //              Most fused clusters of Clifford+T-like circuits are permutations times phases or two independent
-//              2x2 blocks, and so are products of neighbouring ones on <= 3 qubits (Scheduler::merge_blocks).
+//              2x2 blocks, and so are products of neighbouring ones on a few qubits (Scheduler::merge_blocks).
+//              k <= 3: one lane owns a whole group of 2^k amplitudes (reads, then writes).  k = 4, 5: the 2^k rows of a
+//              group are split over 2 or 4 lanes (8 rows each, in different waves), with a workgroup barrier between
+//              everybody's reads and the writes — the same LDS traffic per amplitude for a block that folds more gates.
 //   TOP_SCALE  no qubit inside the tile: a factor per tile, applied while the tile is staged in.
 // BANKS.  A block may also depend on up to two qubits OUTSIDE the tile, provided it is block-diagonal in them (a CX
 // whose control is outside, any diagonal gate): such a qubit is constant over a tile, so it merely selects which
@@ -36,22 +39,23 @@ struct M4 { double re[16], im[16]; };
 // TOP_SCALE uses the same selection and reads its factor from re/im[bank][0].
 enum : int32_t { TOP_G1 = 1, TOP_G2 = 2, TOP_DIAG1 = 3, TOP_SP = 4, TOP_SCALE = 5 };
 constexpr int kMaxBanks = 4;
+constexpr int kMaxOpQ = 5;                      // TOP_SP blocks span 2..5 tile qubits
+constexpr int kMaxOpEntries = 4 << kMaxOpQ;     // 4 entries for each of 32 rows
 struct TileOp {
     int32_t kind;
-    int32_t nq;        // qubits of the block inside the tile (0..3)
-    int32_t b[3];      // tile-local bits, ascending
-    int32_t terms;     // TOP_SP: entries per row (1, 2, 4), the same for every bank
-    int32_t nsel;      // 0..2 selecting qubits
-    int32_t selbit[2]; // their global index bits, most significant bank bit first
+    int32_t nq;           // qubits of the block inside the tile (0..5)
+    int32_t b[kMaxOpQ];   // tile-local bits, ascending
+    int32_t terms;        // TOP_SP: entries per row (1, 2, 4), the same for every bank
+    int32_t nsel;         // 0..2 selecting qubits
+    int32_t selbit[2];    // their global index bits, most significant bank bit first
     int32_t ident;
-    int32_t meta[kMaxBanks];
-    int32_t pad[2];
-    uint32_t rowoff[8];           // TOP_SP: LDS BYTE offset of row r's slot
-    uint32_t off[kMaxBanks][32];  // TOP_SP: LDS BYTE offset of entry e's operand slot
-    double re[kMaxBanks][32];
-    double im[kMaxBanks][32];
+    uint32_t meta[kMaxBanks];
+    uint32_t rowoff[1 << kMaxOpQ];            // TOP_SP: LDS BYTE offset of row r's slot
+    uint32_t off[kMaxBanks][kMaxOpEntries];   // TOP_SP: LDS BYTE offset of entry e's operand slot
+    double re[kMaxBanks][kMaxOpEntries];
+    double im[kMaxBanks][kMaxOpEntries];
 };
-static_assert(sizeof(TileOp) == 64 + 32 + 512 + 2048, "TileOp layout is shared with the device");
+static_assert(sizeof(TileOp) == 64 + 128 + 2048 + 8192, "TileOp layout is shared with the device");
 
 constexpr int kMaxTileHigh = 10; // high (non-contiguous) qubits per tile
 struct TileGeom {

@@ -105,6 +105,7 @@ Scheduler::Scheduler(const SchedConfig &cfg) : cfg_(cfg), open_(cfg.n > 0 ? cfg.
     if (const char *v = getenv("QSIM_SCHED_LOCAL")) cfg_.local_iters = atoi(v);
     if (const char *v = getenv("QSIM_SCHED_OBJ")) cfg_.objective = atoi(v);
     if (const char *v = getenv("QSIM_SCHED_MERGE")) cfg_.merge = atoi(v);
+    if (const char *v = getenv("QSIM_SCHED_MERGEQ")) cfg_.merge_qubits = atoi(v);
 }
 
 void Scheduler::close(int idx) {
@@ -235,22 +236,17 @@ void Scheduler::finish(std::vector<Pass> &out) {
 
 // ---- tile blocks ----------------------------------------------------------------------------------------
 int TileBlock::max_row_nnz() const {
-    const int d = dim();
     int best = 0;
     for (int v = 0; v < banks(); v++)
-        for (int r = 0; r < d; r++) {
-            int cnt = 0;
-            for (int c = 0; c < d; c++) cnt += !is_zero(bank[v][d * r + c]);
-            best = std::max(best, cnt);
-        }
+        for (int r = 0; r < dim(); r++) best = std::max(best, rows[v][r].n);
     return best;
 }
 
 bool TileBlock::bank_is_identity(int v) const {
-    const int d = dim();
-    for (int r = 0; r < d; r++)
-        for (int c = 0; c < d; c++)
-            if (r == c ? !is_one(bank[v][d * r + c]) : !is_zero(bank[v][d * r + c])) return false;
+    for (int r = 0; r < dim(); r++) {
+        const Row &row = rows[v][r];
+        if (row.n != 1 || row.col[0] != r || !is_one(row.val[0])) return false;
+    }
     return true;
 }
 
@@ -265,7 +261,7 @@ void TileBlock::full_matrix(cd *out) const {
     std::fill(out, out + (size_t)D * D, cd(0, 0));
     for (int v = 0; v < banks(); v++)
         for (int r = 0; r < d; r++)
-            for (int c = 0; c < d; c++) out[(size_t)(v * d + r) * D + (v * d + c)] = bank[v][d * r + c];
+            for (int j = 0; j < rows[v][r].n; j++) out[(size_t)(v * d + r) * D + (v * d + rows[v][r].col[j])] = rows[v][r].val[j];
 }
 
 // Splits a fused op (1 or 2 qubits at level 3) by the tile: qubits in `inside` stay matrix indices, the others become
@@ -289,8 +285,13 @@ static TileBlock to_block(const FusedOp &op, uint64_t inside) {
         return idx;
     };
     for (int v = 0; v < (1 << t.ns); v++)
-        for (int r = 0; r < d; r++)
-            for (int c = 0; c < d; c++) t.bank[v][d * r + c] = op.m[D * compose(v, r) + compose(v, c)];
+        for (int r = 0; r < d; r++) {
+            TileBlock::Row &row = t.rows[v][r];
+            for (int c = 0; c < d; c++) {
+                const cd z = op.m[D * compose(v, r) + compose(v, c)];
+                if (!is_zero(z)) { row.col[row.n] = (uint8_t)c; row.val[row.n++] = z; } // d <= 4 = kMaxRowNnz
+            }
+        }
     return t;
 }
 
@@ -376,7 +377,10 @@ void Scheduler::tile_pass(const std::vector<FusedOp> &ops, uint64_t hset, const 
         bool folded = false;
         for (TileBlock &sc : scalars)
             if (sc.ns == tb.ns && sc.s[0] == tb.s[0] && sc.s[1] == tb.s[1]) {
-                for (int v = 0; v < tb.banks(); v++) sc.bank[v][0] = tb.bank[v][0] * sc.bank[v][0];
+                for (int v = 0; v < tb.banks(); v++) { // 1x1 banks: the factors multiply
+                    const cd z = tb.at(v, 0, 0) * sc.at(v, 0, 0);
+                    sc.rows[v][0].n = 1; sc.rows[v][0].col[0] = 0; sc.rows[v][0].val[0] = z;
+                }
                 sc.gates += tb.gates;
                 folded = true;
                 break;
@@ -467,6 +471,7 @@ void Scheduler::build_passes(const PassSink &sink) {
     // Blocks a pass with high-qubit set S executes, in index order (a valid execution order: a block runs only if
     // every earlier pending block on its qubits ran), and their score.
     std::vector<long> picks, best_picks;
+    bool endgame = false; // few blocks left: search the last pass sets so that no straggler pass remains
     auto eval = [&](const std::vector<char> &dn, size_t from, size_t to, uint64_t S, std::vector<long> *out) {
         uint64_t blocked = 0;
         int score = 0, cnt = 0;
@@ -486,7 +491,7 @@ void Scheduler::build_passes(const PassSink &sink) {
     };
     auto eval_ahead = [&](size_t from, size_t to, uint64_t S, std::vector<long> *out) {
         int score = eval(done, from, to, S, out ? out : &picks);
-        if (cfg_.lookahead > 0) {
+        if (cfg_.lookahead > 0 || endgame) {
             trial = done;
             for (long i : (out ? *out : picks)) trial[(size_t)i] = 1;
             std::vector<char> t2 = trial;
@@ -528,9 +533,15 @@ void Scheduler::build_passes(const PassSink &sink) {
         // 2. local search over the qubit set: swap one chosen high qubit for one left out while the pass (and, with
         //    lookahead, the greedy passes after it) executes more.  The host has milliseconds per pass to spend here:
         //    the GPU is busy with the previous pass for ~7 ms at n = 30.
-        if (cfg_.local_iters > 0 && __builtin_popcountll(hset) >= 2) {
+        {
+            size_t left = 0;
+            for (size_t i = first; i < m && left <= 2 * (size_t)cfg_.tile_max_ops; i++) left += !done[i];
+            endgame = left <= 2 * (size_t)cfg_.tile_max_ops;
+        }
+        const int iters = endgame ? std::max(cfg_.local_iters, 3) : cfg_.local_iters;
+        if (iters > 0 && __builtin_popcountll(hset) >= 2) {
             int best = eval_ahead(first, end, hset, &best_picks);
-            for (int it = 0; it < cfg_.local_iters; it++) {
+            for (int it = 0; it < iters; it++) {
                 uint64_t bestS = hset;
                 for (uint64_t in = hset; in; in &= in - 1) {
                     const uint64_t qi = in & (0 - in);
@@ -574,34 +585,50 @@ void Scheduler::build_passes(const PassSink &sink) {
 // rest of the scan.  Selecting qubits are merged too: the product has one bank per value of the union (at most two).
 namespace {
 
-// embeds bank `v` (given over the selector list ss[0..nss)) of `b` into the space of tile qubits qs[0..k) (descending)
-void embed_bank(const TileBlock &b, const int *qs, int k, const int *ss, int nss, int v, cd *out) {
-    int bv = 0; // the block's own bank index under the joint selector value v
-    for (int a = 0; a < b.ns; a++)
-        for (int j = 0; j < nss; j++)
-            if (ss[j] == b.s[a]) bv |= ((v >> (nss - 1 - j)) & 1) << (b.ns - 1 - a);
-    const int D = 1 << k, d = b.dim();
-    int pos[3] = {0, 0, 0}; // bit position (inside the k-bit index) of each of the block's qubits
-    for (int a = 0; a < b.nq; a++)
-        for (int j = 0; j < k; j++)
-            if (qs[j] == b.q[a]) pos[a] = k - 1 - j;
-    int opmask = 0;
-    for (int a = 0; a < b.nq; a++) opmask |= 1 << pos[a];
-    auto sub = [&](int idx) {
+// Row `r` of bank `bv` of block `b`, embedded into the space of the tile qubits qs[0..k) (descending): the block acts
+// on its own qubits and as the identity on the rest, so the row keeps its entries with the spectator bits copied.
+struct Embedding {
+    int pos[kMaxBlockQ]; // bit position (inside the k-bit index) of each of the block's qubits
+    int mask = 0;
+    Embedding(const TileBlock &b, const int *qs, int k) {
+        for (int a = 0; a < b.nq; a++) {
+            pos[a] = 0;
+            for (int j = 0; j < k; j++)
+                if (qs[j] == b.q[a]) pos[a] = k - 1 - j;
+            mask |= 1 << pos[a];
+        }
+    }
+    int sub(const TileBlock &b, int idx) const { // idx restricted to the block's qubits, most significant first
         int r = 0;
         for (int a = 0; a < b.nq; a++) r = (r << 1) | ((idx >> pos[a]) & 1);
         return r;
-    };
-    for (int r = 0; r < D; r++)
-        for (int c = 0; c < D; c++)
-            out[D * r + c] = ((r & ~opmask) == (c & ~opmask)) ? b.bank[bv][d * sub(r) + sub(c)] : cd(0, 0);
+    }
+    int spread(const TileBlock &b, int sub_idx) const {
+        int r = 0;
+        for (int a = 0; a < b.nq; a++) r |= ((sub_idx >> (b.nq - 1 - a)) & 1) << pos[a];
+        return r;
+    }
+};
+
+// the block's own bank index under the joint selector value v over ss[0..nss)
+int own_bank(const TileBlock &b, const int *ss, int nss, int v) {
+    int bv = 0;
+    for (int a = 0; a < b.ns; a++)
+        for (int j = 0; j < nss; j++)
+            if (ss[j] == b.s[a]) bv |= ((v >> (nss - 1 - j)) & 1) << (b.ns - 1 - a);
+    return bv;
 }
 
 } // namespace
 
 void Scheduler::merge_blocks(std::vector<TileBlock> &blocks) const {
-    constexpr int kMaxQ = 3, kMaxNnz = 4, kMaxSel = 2;
+    // Tiles of fewer than 2^11 amplitudes keep to 3 qubits: the forms for 4 and 5 split a group's rows over 2 or 4
+    // lanes' worth of waves and need 2^(B-5) >= 64 groups.
+    const int B = std::min(cfg_.tile_bits, cfg_.n);
+    const int kMaxQ = B >= 11 ? std::min(cfg_.merge_qubits, kMaxBlockQ) : 3;
+    constexpr int kMaxSel = 2;
     std::vector<TileBlock> rem(blocks), next, out;
+    TileBlock m;
     while (!rem.empty()) {
         TileBlock cur = rem[0];
         uint64_t blocked = 0;
@@ -612,34 +639,61 @@ void Scheduler::merge_blocks(std::vector<TileBlock> &blocks) const {
             if (qm & blocked) { blocked |= qm; next.push_back(op); continue; }
             const uint64_t un = cur.in_mask() | qm, us = cur.sel_mask() | op.sel_mask();
             bool merged = false;
-            if (__builtin_popcountll(un) <= kMaxQ && __builtin_popcountll(us) <= kMaxSel &&
-                cur.max_row_nnz() * op.max_row_nnz() <= 2 * kMaxNnz) {
-                int qs[3], k = 0, ss[2], nss = 0;
+            if (__builtin_popcountll(un) <= kMaxQ && __builtin_popcountll(us) <= kMaxSel) {
+                int qs[kMaxBlockQ], k = 0, ss[2], nss = 0;
                 for (int b = 63; b >= 0; b--) {
                     if (un >> b & 1ULL) qs[k++] = b;
                     if (us >> b & 1ULL) ss[nss++] = b;
                 }
                 const int D = 1 << k;
-                TileBlock m;
+                m = TileBlock();
                 m.nq = k;
                 m.ns = nss;
                 for (int a = 0; a < k; a++) m.q[a] = qs[a];
                 for (int a = 0; a < nss; a++) m.s[a] = ss[a];
                 m.gates = cur.gates + op.gates;
-                for (int v = 0; v < (1 << nss); v++) {
-                    cd a[64], b2[64];
-                    embed_bank(cur, qs, k, ss, nss, v, a);
-                    embed_bank(op, qs, k, ss, nss, v, b2);
-                    for (int r = 0; r < D; r++)
-                        for (int c = 0; c < D; c++) {
-                            cd acc(0, 0);
-                            for (int t = 0; t < D; t++)
-                                if (!is_zero(b2[D * r + t]) && !is_zero(a[D * t + c])) acc += b2[D * r + t] * a[D * t + c];
-                            m.bank[v][D * r + c] = acc;
+                const Embedding ea(cur, qs, k), eb(op, qs, k);
+                bool fits = true;
+                for (int v = 0; v < (1 << nss) && fits; v++) {
+                    const int va = own_bank(cur, ss, nss, v), vb = own_bank(op, ss, nss, v);
+                    for (int r = 0; r < D && fits; r++) { // row r of (op after cur) = sum_t op[r][t] * cur[t][.]
+                        int cols[kMaxRowNnz * kMaxRowNnz], n = 0;
+                        cd vals[kMaxRowNnz * kMaxRowNnz];
+                        const TileBlock::Row &rb = op.rows[vb][eb.sub(op, r)];
+                        for (int jb = 0; jb < rb.n; jb++) {
+                            const int t = (r & ~eb.mask) | eb.spread(op, rb.col[jb]);
+                            const TileBlock::Row &ra = cur.rows[va][ea.sub(cur, t)];
+                            for (int ja = 0; ja < ra.n; ja++) {
+                                const int c = (t & ~ea.mask) | ea.spread(cur, ra.col[ja]);
+                                const cd z = rb.val[jb] * ra.val[ja];
+                                int e = 0;
+                                while (e < n && cols[e] != c) e++;
+                                if (e == n) { cols[n] = c; vals[n++] = z; }
+                                else vals[e] += z;
+                            }
                         }
+                        TileBlock::Row &row = m.rows[v][r];
+                        row.n = 0;
+                        for (int e = 0; e < n; e++) {
+                            if (is_zero(vals[e])) continue; // exact cancellation
+                            // one LDS trip evaluates at most kMaxRowNnz entries per row — except on two qubits, where
+                            // that is all four columns anyway
+                            if (row.n == kMaxRowNnz) { fits = false; break; }
+                            row.col[row.n] = (uint8_t)cols[e];
+                            row.val[row.n++] = vals[e];
+                        }
+                    }
                 }
-                // a 3-qubit product is only worth it while it stays sparse; 1- and 2-qubit products always fold
-                if (k <= 2 || m.max_row_nnz() <= kMaxNnz) {
+                if (fits) {
+                    for (int v = 0; v < (1 << nss); v++) // keep every row's entries in ascending column order
+                        for (int r = 0; r < D; r++) {
+                            TileBlock::Row &row = m.rows[v][r];
+                            for (int x = 1; x < row.n; x++)
+                                for (int y = x; y > 0 && row.col[y - 1] > row.col[y]; y--) {
+                                    std::swap(row.col[y - 1], row.col[y]);
+                                    std::swap(row.val[y - 1], row.val[y]);
+                                }
+                        }
                     cur = m;
                     merged = true;
                 }

@@ -47,19 +47,33 @@ struct FusedOp {
 
 // One block of a tile pass = one trip through LDS.  `q` are its qubits inside the tile; `s` are qubits OUTSIDE the tile
 // that the block is block-diagonal in: constant over a tile, they only select which bank (sub-block on `q`) applies.
-// nq == 0: a tile-uniform factor (bank[v][0]).
+// nq == 0: a tile-uniform factor (entry (0,0) of each bank).  Stored by rows, at most kMaxRowNnz entries each: that is
+// what one LDS trip of k_tile can evaluate (a dense 4x4 on two qubits is the fullest case), and it keeps the products
+// of merge_blocks cheap on up to kMaxBlockQ qubits.
+constexpr int kMaxBlockQ = 5, kMaxRowNnz = 4;
 struct TileBlock {
     int nq = 0;
-    int q[3] = {-1, -1, -1}; // descending: q[0] is the most significant bit of the row/column index
+    int q[kMaxBlockQ] = {-1, -1, -1, -1, -1}; // descending: q[0] is the most significant bit of the row/column index
     int ns = 0;
-    int s[2] = {-1, -1};     // descending: s[0] is the most significant bit of the bank index
-    cd bank[kMaxBanks][64];  // row-major (1 << nq) x (1 << nq)
+    int s[2] = {-1, -1};                      // descending: s[0] is the most significant bit of the bank index
+    struct Row {
+        int n = 0;
+        uint8_t col[kMaxRowNnz];
+        cd val[kMaxRowNnz];
+    };
+    Row rows[kMaxBanks][1 << kMaxBlockQ];
     uint32_t gates = 0;
 
     int dim() const { return 1 << nq; }
     int banks() const { return 1 << ns; }
     uint64_t in_mask() const { uint64_t m = 0; for (int a = 0; a < nq; a++) m |= 1ULL << q[a]; return m; }
     uint64_t sel_mask() const { uint64_t m = 0; for (int a = 0; a < ns; a++) m |= 1ULL << s[a]; return m; }
+    cd at(int v, int r, int c) const {
+        const Row &row = rows[v][r];
+        for (int j = 0; j < row.n; j++)
+            if (row.col[j] == c) return row.val[j];
+        return cd(0, 0);
+    }
     int max_row_nnz() const;    // over all banks
     bool bank_is_identity(int v) const;
     bool is_identity() const;   // every bank
@@ -90,7 +104,8 @@ struct SchedConfig {
     int tile_low_bits = 3;
     int tile_max_ops = 32;
     int window = 512;  // clusters scanned ahead when grouping a pass
-    int merge = 1;     // level 3: merge neighbouring blocks of a pass into sparse <=3-qubit blocks
+    int merge = 1;     // level 3: merge neighbouring blocks of a pass into sparse blocks of up to merge_qubits tile qubits
+    int merge_qubits = 5;
     int rollout = 8;   // level 3: candidates tried (each by greedily finishing the pass) when a new qubit must be admitted; 0 = off
     int pad_from = 10; // first bit tried when unused tile slots are filled (below tile_low_bits: tile_low_bits)
     int lookahead = 0; // level 3: further passes (built greedily) whose reach is added to a candidate's score

@@ -190,8 +190,8 @@ def test_tile_passes_respect_geometry_limits():
                 return out
             high = {q for o in ops for q in mixing(o[3], o[4]) if q >= 6}
             assert len(high) <= 4
-            # a block: at most 3 qubits it mixes (they must be inside the tile) plus at most 2 selecting ones, and at
+            # a block: at most 5 qubits it mixes (they must be inside the tile) plus at most 2 selecting ones, and at
             # most 4 entries per row (one LDS trip of the sparse form; dense 4x4 for two qubits)
             for o in ops:
-                assert len(mixing(o[3], o[4])) <= 3 and len(o[3]) <= 5
+                assert len(mixing(o[3], o[4])) <= 5 and len(o[3]) <= 7
                 assert (o[4] != 0).sum(axis=1).max() <= 4

@@ -9,7 +9,7 @@ cfgs = [tuple(int(x) for x in a.split(',')) for a in sys.argv[1:]] or [(11, 4, 2
 for cfg in cfgs:
     B, L, T = cfg[:3]
     G = cfg[3] if len(cfg) > 3 else 0
-    with Simulator(n, fuse=3, profile=True, tile_bits=B, tile_low_bits=L, tile_threads=T, tile_max_ops=64, grid_cap=max(G, 0), precision=prec) as sim:
+    with Simulator(n, fuse=3, profile=True, tile_bits=B, tile_low_bits=L, tile_threads=T, tile_max_ops=int(os.environ.get('GEO_MAXOPS', 64)), grid_cap=max(G, 0), precision=prec) as sim:
         def body():
             sim.reset(); sim.run(c); sim.flush()
         body(); sim.sync(); sim.reset_stats()

@@ -180,7 +180,7 @@ extern "C" int qsim_set_option(qsim_state *s, int option, long value) {
         s->max_pending = value;
         break;
     case QSIM_OPT_TILE_MAX_OPS:
-        if (value < 1 || value > 1024) return fail(QSIM_ERR_ARG, "tile_max_ops %ld not in 1..1024", value);
+        if (value < 1 || value > (long)kOpsCap) return fail(QSIM_ERR_ARG, "tile_max_ops %ld not in 1..%zu", value, kOpsCap);
         s->tile_max_ops = (int)value;
         break;
     case QSIM_OPT_GRID_CAP:

@@ -545,3 +545,45 @@ def test_randomised_geometry_sweep(oracle, tmp_path):
         assert err < TOL, (case, n, depth, vocab, fuse, opts, err)
         worst = max(worst, err)
     assert worst < 1e-12
+
+
+@pytest.mark.parametrize("opts", [{}, {"tile_bits": 11, "tile_low_bits": 3}, {"tile_bits": 13, "tile_low_bits": 4},
+                                  {"tile_bits": 10, "tile_low_bits": 2}, {"tile_bits": 12, "tile_low_bits": 3, "tile_max_ops": 64}])
+def test_out_of_tile_selectors_and_wide_blocks(oracle, tmp_path, opts):
+    """Blocks that are block-diagonal in a qubit leave it outside the tile (coefficient banks picked per tile), and
+    neighbouring blocks are merged on up to 5 tile qubits.  A circuit built to stress both: controls and diagonal gates
+    on the TOP qubits of a 22-qubit register (never tile qubits unless mixed), targets and Hadamards spread below, long
+    CX ladders over 4-5 adjacent qubits so that wide merged blocks appear."""
+    n = 22
+    rng = np.random.default_rng(2024)
+    lines = ["OPENQASM 3.0;", 'include "stdgates.inc";', f"qubit[{n}] q;"]
+    for q in range(n):
+        lines.append(f"h q[{q}];")
+    for rep in range(40):
+        top = int(rng.integers(14, n))
+        for _ in range(6):
+            t = int(rng.integers(0, 14))
+            lines.append(f"cx q[{top}], q[{t}];")
+            lines.append(f"{rng.choice(['t', 's', 'z', 'tdg'])} q[{top}];")
+            lines.append(f"rz({rng.uniform(-3, 3)!r}) q[{int(rng.integers(14, n))}];")
+            lines.append(f"{rng.choice(['h', 'sx', 'x', 't'])} q[{t}];")
+        a = int(rng.integers(3, 10))
+        for k in range(4):  # ladder on a..a+4
+            lines.append(f"cx q[{a + k}], q[{a + k + 1}];")
+            lines.append(f"t q[{a + k + 1}];")
+        lines.append(f"h q[{top}];")  # now the top qubit is mixed: it has to enter a tile
+    path = str(tmp_path / "sel.qasm")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    _, want, _, _ = oracle.run_qasm(path)
+    got = run_qasm(path, fuse=3, **opts)
+    assert np.max(np.abs(got - want)) < TOL
+    # the schedule really uses both features (checked on the host: no GPU needed for this part)
+    sched = Circuit.from_file(path).schedule(fuse=3, tile_bits=opts.get("tile_bits", 12), tile_low_bits=opts.get("tile_low_bits", 3))
+    tile_ops = [s for s in sched if s[1] == "tile"]
+    assert any(len(s[3]) >= 4 for s in tile_ops)
+    if opts.get("tile_bits", 12) >= 11:
+        def mixing(qs, U):
+            r, c = np.nonzero(U)
+            return [q for a, q in enumerate(qs) if np.any((r ^ c) & (1 << (len(qs) - 1 - a)))]
+        assert any(len(mixing(s[3], s[4])) < len(s[3]) for s in tile_ops)

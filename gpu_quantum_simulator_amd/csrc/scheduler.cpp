@@ -98,6 +98,8 @@ void Scheduler::cx4(bool control_is_hi, cd out[16]) {
 // built on the host, so that is irrelevant.  Zeros stay exact: every term of an off-diagonal entry of a
 // product of diagonal matrices has an exact-zero factor.
 
+// The QSIM_SCHED_* variables override the search parameters for experiments (tools/); they are not
+// part of the API and change the pass count, never the result.
 Scheduler::Scheduler(const SchedConfig &cfg) : cfg_(cfg), open_(cfg.n > 0 ? cfg.n : 0, -1) {
     if (const char *v = getenv("QSIM_SCHED_LOOKAHEAD")) cfg_.lookahead = atoi(v);
     if (const char *v = getenv("QSIM_SCHED_ROLLOUT")) cfg_.rollout = atoi(v);

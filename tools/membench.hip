@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <initializer_list>
+#include <type_traits>
 #include <vector>
 
 typedef double amp_t __attribute__((ext_vector_type(2)));
@@ -123,6 +125,80 @@ __global__ __launch_bounds__(T) void k_tile_glds2(amp_t *v, uint64_t ntiles, int
     }
 }
 
+
+// ---- the tile access pattern of k_tile: 512 runs of 8 amplitudes per tile, run positions = index bits HIGH (constant
+// masks so the bit deposits fold to a few shifts), consecutive tiles differ in the remaining (outer) bits -------------
+template <uint64_t MASK>
+__device__ __forceinline__ uint64_t dep(uint64_t x) {
+    uint64_t out = 0, m = MASK;
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        if (!m) break;
+        const uint64_t low = m & (0 - m);
+        if (x & 1ULL) out |= low;
+        x >>= 1;
+        m &= m - 1;
+    }
+    return out;
+}
+
+template <uint64_t HIGH, int NQ>
+__device__ __forceinline__ uint64_t tile_addr(uint64_t tile, uint32_t slot) {
+    constexpr uint64_t ALL = (1ULL << NQ) - 1ULL;
+    constexpr uint64_t OUTER = ALL & ~(HIGH | 7ULL);
+    return dep<OUTER>(tile) | dep<HIGH>(slot >> 3) | (slot & 7u);
+}
+
+// one amplitude per thread, tile pattern, huge grid
+template <uint64_t HIGH, int NQ>
+__global__ __launch_bounds__(256) void k_simple_tile(amp_t *v, double c) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t a = tile_addr<HIGH, NQ>(t >> 12, (uint32_t)(t & 4095));
+    v[a] = scale(v[a], c);
+}
+
+// 8 loads then 8 stores per thread, a 512-thread workgroup owns a tile, TPW consecutive tiles per workgroup, no LDS
+template <uint64_t HIGH, int NQ>
+__global__ __launch_bounds__(512) void k_deep_tile(amp_t *v, uint64_t ntiles, int tpw, double c) {
+    for (int j = 0; j < tpw; j++) {
+        const uint64_t tile = (uint64_t)blockIdx.x * tpw + j;
+        if (tile >= ntiles) return;
+        amp_t a[8];
+        uint64_t ad[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { ad[k] = tile_addr<HIGH, NQ>(tile, threadIdx.x + k * 512); a[k] = v[ad[k]]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[ad[k]] = scale(a[k], c);
+    }
+}
+
+// the same through LDS with the next tile prefetched into registers (the structure of k_tile with its blocks skipped)
+template <uint64_t HIGH, int NQ>
+__global__ __launch_bounds__(512) void k_lds_tile(amp_t *v, uint64_t ntiles, int tpw, double c) {
+    extern __shared__ amp_t lds[];
+    const uint64_t first = (uint64_t)blockIdx.x * tpw;
+    uint64_t last = first + tpw;
+    if (last > ntiles) last = ntiles;
+    if (first >= last) return;
+    amp_t a[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) a[k] = v[tile_addr<HIGH, NQ>(first, threadIdx.x + k * 512)];
+    for (uint64_t t = first; t < last; t++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) lds[threadIdx.x + k * 512] = a[k];
+        __syncthreads();
+        if (t + 1 < last) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) a[k] = v[tile_addr<HIGH, NQ>(t + 1, threadIdx.x + k * 512)];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[tile_addr<HIGH, NQ>(t, threadIdx.x + k * 512)] = scale(lds[(threadIdx.x + k * 512) ^ 1], c);
+        __syncthreads();
+    }
+}
+
+constexpr uint64_t bits(std::initializer_list<int> l) { uint64_t m = 0; for (int b : l) m |= 1ULL << b; return m; }
+
 template <typename F>
 static double time_ms(F launch, int reps) {
     hipEvent_t a, b;
@@ -189,6 +265,26 @@ int main(int argc, char **argv) {
         report(nm, time_ms([&] { hipLaunchKernelGGL((k_tile_glds<8, 256>), dim3(grid), dim3(256), 32768, 0, v, nt32, tpw, c); }, reps));
         snprintf(nm, sizeof nm, "tile glds 2x32K T=512 tpw=%d (2 WG/CU)", tpw);
         report(nm, time_ms([&] { hipLaunchKernelGGL((k_tile_glds2<4, 512>), dim3(grid), dim3(512), 65536, 0, v, nt32, tpw, c); }, reps));
+    }
+
+    if (n == 30) {
+        auto pattern = [&](const char *name, auto tag) {
+            constexpr uint64_t H = decltype(tag)::value;
+            char nm[128];
+            snprintf(nm, sizeof nm, "%s: simple 1/thread", name);
+            report(nm, time_ms([&] { hipLaunchKernelGGL((k_simple_tile<H, 30>), dim3((unsigned)(N / 256)), dim3(256), 0, 0, v, c); }, reps));
+            for (int tpw : {1, 8}) {
+                const unsigned grid = (unsigned)((ntiles + tpw - 1) / tpw);
+                snprintf(nm, sizeof nm, "%s: 8 loads/8 stores, no LDS, tpw=%d", name, tpw);
+                report(nm, time_ms([&] { hipLaunchKernelGGL((k_deep_tile<H, 30>), dim3(grid), dim3(512), 0, 0, v, ntiles, tpw, c); }, reps));
+                snprintf(nm, sizeof nm, "%s: through LDS + prefetch, tpw=%d", name, tpw);
+                report(nm, time_ms([&] { hipLaunchKernelGGL((k_lds_tile<H, 30>), dim3(grid), dim3(512), 65536, 0, v, ntiles, tpw, c); }, reps));
+            }
+        };
+        pattern("high=3..11 (contiguous)", std::integral_constant<uint64_t, bits({3, 4, 5, 6, 7, 8, 9, 10, 11})>{});
+        pattern("high=bench pass 2", std::integral_constant<uint64_t, bits({5, 10, 12, 15, 17, 18, 19, 20, 29})>{});
+        pattern("high=bench pass 12", std::integral_constant<uint64_t, bits({4, 8, 12, 13, 16, 17, 19, 22, 24})>{});
+        pattern("high=21..29 (top)", std::integral_constant<uint64_t, bits({21, 22, 23, 24, 25, 26, 27, 28, 29})>{});
     }
     CK(hipFree(v));
     return 0;

@@ -580,7 +580,7 @@ void Scheduler::build_passes(const PassSink &sink) {
 
 // ---- sparse merging inside a pass -------------------------------------------------------------------------
 // Most fused clusters are permutations-times-phases or two independent 2x2 blocks (exact zeros), so the product
-// of neighbours on <= 3 tile qubits usually still has <= 4 entries per row.  Such a product costs ONE trip through
+// of neighbours on a few tile qubits usually still has <= 4 entries per row.  Such a product costs ONE trip through
 // LDS in k_tile instead of one per factor, which is what bounds a pass once it carries more than ~6 blocks.
 // Order: a block may hop over earlier blocks it shares no TILE qubit with (they commute: outside the tile every block
 // of the pass is block-diagonal); everything it shares a tile qubit with and cannot join blocks those qubits for the

@@ -75,6 +75,7 @@ SIGNATURES = {
     "qsim_cluster_sync": (c_int, [c_void_p]),
     "qsim_cluster_read": (c_int, [c_void_p, c_uint64, c_uint64, _DP]),
     "qsim_cluster_norm2": (c_int, [c_void_p, _DP]),
+    "qsim_cluster_sample": (c_int, [c_void_p, _DP, c_long, POINTER(c_uint64)]),
     "qsim_cluster_exchange_stats": (c_int, [c_void_p, POINTER(c_uint64), _DP]),
     "qsim_cluster_error": (c_char_p, []),
     "qsim_shard_plan_create": (c_int, [POINTER(c_void_p), c_void_p, c_int]),

@@ -428,6 +428,77 @@ extern "C" int qsim_cluster_read(qsim_cluster *c, uint64_t first, uint64_t count
     return QSIM_OK;
 }
 
+// measurement() of quantum_simulator.c:270-283 on a sharded state, in LOGICAL index order (the order the reference's
+// cumulative distribution runs in, whatever the qubit map of the last run left behind).  Each shard is streamed to the
+// host once in 64 MiB pieces and contributes to the sums of the 2^12-amplitude logical blocks it holds a part of — the
+// "P partial sums" of SURVEY 8f row 1, added in shard order; a draw then fetches only its own block.
+extern "C" int qsim_cluster_sample(qsim_cluster *c, const double *randoms, long shots, uint64_t *out) {
+    if (!c || (shots > 0 && (!randoms || !out))) return cfail(QSIM_ERR_ARG, "NULL argument");
+    constexpr int kBlockBits = 12;
+    const int bb = c->n < kBlockBits ? c->n : kBlockBits;
+    const uint64_t N = 1ULL << c->n, nblocks = N >> bb, bsize = 1ULL << bb, M = 1ULL << c->m;
+    std::vector<int> inv(c->n); // physical bit -> logical qubit
+    for (int q = 0; q < c->n; q++) inv[c->pos[q]] = q;
+    // logical index of a physical index, by halves of the local bits (a bit permutation is linear over OR)
+    const int lo_bits = c->m < 11 ? c->m : 11;
+    std::vector<uint64_t> t_lo(1ULL << lo_bits);
+    for (uint64_t j = 0; j < t_lo.size(); j++) {
+        uint64_t l = 0;
+        for (int b = 0; b < lo_bits; b++) l |= ((j >> b) & 1ULL) << inv[b];
+        t_lo[j] = l;
+    }
+    auto logical_hi = [&](uint64_t ph_hi) { // ph_hi = physical index >> lo_bits
+        uint64_t l = 0;
+        for (int b = lo_bits; b < c->n; b++) l |= ((ph_hi >> (b - lo_bits)) & 1ULL) << inv[b];
+        return l;
+    };
+    std::vector<double> prefix(nblocks, 0.0);
+    const uint64_t piece = M < (1ULL << 22) ? M : (1ULL << 22);
+    std::vector<double> buf(2 * piece);
+    for (int r = 0; r < c->P; r++)
+        for (uint64_t at = 0; at < M; at += piece) {
+            const int rc = qsim_read(c->shard[r], at, piece, buf.data());
+            if (rc) return cfail(rc, "%s", qsim_last_error());
+            for (uint64_t j = 0; j < piece; j++) {
+                const uint64_t ph = ((uint64_t)r << c->m) | (at + j);
+                const uint64_t l = logical_hi(ph >> lo_bits) | t_lo[ph & (t_lo.size() - 1)];
+                prefix[l >> bb] += buf[2 * j] * buf[2 * j] + buf[2 * j + 1] * buf[2 * j + 1];
+            }
+        }
+    double acc = 0.0;
+    for (uint64_t b = 0; b < nblocks; b++) { acc += prefix[b]; prefix[b] = acc; } // cumulative at the END of block b
+    std::vector<double> blk(2 * bsize);
+    uint64_t cached = ~0ULL;
+    for (long k = 0; k < shots; k++) {
+        const double rnd = randoms[k];
+        uint64_t lo = 0, hi = nblocks;
+        while (lo < hi) { // first block whose end value is non-zero and >= r (quantum_simulator.c:279)
+            const uint64_t mid = (lo + hi) >> 1;
+            if (prefix[mid] == 0.0 || prefix[mid] < rnd) lo = mid + 1;
+            else hi = mid;
+        }
+        uint64_t idx = N - 1;
+        bool found = false;
+        for (uint64_t b = lo; b < nblocks && !found; b++) {
+            if (b != cached) {
+                for (uint64_t i = 0; i < bsize; i++) {
+                    const uint64_t ph = physical_index(c, b * bsize + i);
+                    const int rc = qsim_read(c->shard[ph >> c->m], ph & (M - 1), 1, blk.data() + 2 * i);
+                    if (rc) return cfail(rc, "%s", qsim_last_error());
+                }
+                cached = b;
+            }
+            double cum = b ? prefix[b - 1] : 0.0;
+            for (uint64_t i = 0; i < bsize; i++) {
+                cum += blk[2 * i] * blk[2 * i] + blk[2 * i + 1] * blk[2 * i + 1];
+                if (!(cum == 0.0 || cum < rnd)) { idx = b * bsize + i; found = true; break; }
+            }
+        }
+        out[k] = idx;
+    }
+    return QSIM_OK;
+}
+
 extern "C" int qsim_cluster_norm2(qsim_cluster *c, double *out) {
     if (!c || !out) return cfail(QSIM_ERR_ARG, "NULL argument");
     double tot = 0;

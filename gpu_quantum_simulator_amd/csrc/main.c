@@ -50,7 +50,7 @@ static int dump_text(qsim_state *s, const char *path) {
 }
 
 /* The multi-GPU path of the C host: same stdout contract, state sharded over QSIM_SHARDS shards. */
-static int run_sharded(qsim_circuit *c, int shards, double t_start) {
+static int run_sharded(qsim_circuit *c, int shards, double t_start, long shots) {
     qsim_cluster *cl = NULL;
     const char *v;
     int rc = qsim_cluster_create(&cl, qsim_circuit_num_qubits(c), shards, NULL);
@@ -67,6 +67,24 @@ static int run_sharded(qsim_circuit *c, int shards, double t_start) {
     const double t_exe = wall_seconds() - t_start;
     printf("%lf\n", t_exe);
     fflush(stdout);
+    if ((v = getenv("QSIM_MEASURE")) && *v && atoi(v) && shots > 0) { /* quantum_simulator.c:67-73, on the sharded state */
+        const int nq = qsim_circuit_num_qubits(c);
+        srand((unsigned)time(NULL));
+        for (int i = 0; i < 10; i++) rand();
+        char *bits = (char *)malloc((size_t)nq + 1);
+        double *r = (double *)malloc((size_t)shots * sizeof(double));
+        uint64_t *idx = (uint64_t *)malloc((size_t)shots * sizeof(uint64_t));
+        for (long m = 0; r && m < shots; m++) r[m] = qsim_draw_randn();
+        if (bits && r && idx && qsim_cluster_sample(cl, r, shots, idx) == QSIM_OK) {
+            for (long m = 0; m < shots; m++) {
+                qsim_putb((long long)idx[m], nq, bits);
+                printf("MEASUREMENT: %s (%llu)\n", bits, (unsigned long long)idx[m]);
+            }
+        } else {
+            fprintf(stderr, "qsim: %s\n", qsim_cluster_error());
+        }
+        free(bits); free(r); free(idx);
+    }
     if ((v = getenv("QSIM_DUMP")) && *v) {
         const int n = qsim_circuit_num_qubits(c);
         const uint64_t N = 1ULL << n, chunk = N < (1ULL << 20) ? N : (1ULL << 20);
@@ -118,7 +136,7 @@ int main(int argc, char *argv[]) {
         exit(1);
     }
     const int shards = (v = getenv("QSIM_SHARDS")) && *v ? atoi(v) : 1;
-    if (shards > 1) return run_sharded(c, shards, t_start);
+    if (shards > 1) return run_sharded(c, shards, t_start, argc > 2 ? atol(argv[2]) : 0);
     const int device = (v = getenv("QSIM_DEVICE")) && *v ? atoi(v) : 0;
     const int f32 = (v = getenv("QSIM_PRECISION")) && atoi(v) == 32;
     rc = f32 ? qsim_create_f32(&s, qsim_circuit_num_qubits(c), device) : qsim_create(&s, qsim_circuit_num_qubits(c), device);

@@ -310,6 +310,14 @@ class Cluster:
         self._check(_lib.load().qsim_cluster_norm2(self._h, byref(v)))
         return v.value
 
+    def sample(self, randoms) -> np.ndarray:
+        """measurement() (quantum_simulator.c:270-283) on the sharded state, indices in logical order."""
+        from ctypes import c_uint64
+        r = np.ascontiguousarray(randoms, dtype=np.float64)
+        out = np.zeros(r.size, dtype=np.uint64)
+        self._check(_lib.load().qsim_cluster_sample(self._h, _dp(r), r.size, out.ctypes.data_as(ctypes.POINTER(c_uint64))))
+        return out
+
     def exchange_stats(self):
         from ctypes import c_uint64
         n, b = c_uint64(), c_double()

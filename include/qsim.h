@@ -175,6 +175,10 @@ int qsim_cluster_run_circuit(qsim_cluster *c, const qsim_circuit *circuit);
 int qsim_cluster_sync(qsim_cluster *c);
 int qsim_cluster_read(qsim_cluster *c, uint64_t logical_first, uint64_t count, double *out_re_im);
 int qsim_cluster_norm2(qsim_cluster *c, double *out);
+/* qsim_sample for a sharded state: basis indices in LOGICAL order for random numbers in [0,1] (measurement(),
+ * quantum_simulator.c:270-283).  Streams every shard through the host once (bounded memory), so it costs a D2H of the
+ * whole state: a post-path, not a hot path. */
+int qsim_cluster_sample(qsim_cluster *c, const double *randoms, long shots, uint64_t *out_indices);
 int qsim_cluster_exchange_stats(const qsim_cluster *c, uint64_t *exchanges, double *bytes_per_shard);
 const char *qsim_cluster_error(void);
 /* The plan as an object (host only).  This is what the one-process-per-GPU driver executes: every rank builds the same

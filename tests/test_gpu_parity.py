@@ -587,3 +587,39 @@ def test_out_of_tile_selectors_and_wide_blocks(oracle, tmp_path, opts):
             r, c = np.nonzero(U)
             return [q for a, q in enumerate(qs) if np.any((r ^ c) & (1 << (len(qs) - 1 - a)))]
         assert any(len(mixing(s[3], s[4])) < len(s[3]) for s in tile_ops)
+
+
+@pytest.mark.parametrize("shards", [2, 8])
+def test_measurement_on_sharded_state(oracle, golden_dir, tmp_path, shards):
+    """qsim_cluster_sample: measurement() in LOGICAL order on a state whose qubit map was permuted by exchanges."""
+    from gpu_quantum_simulator_amd import Cluster
+    n = 15
+    path = circuits.random_circuit_file(str(tmp_path / "c.qasm"), n, 500, 93, "all")
+    _, want_state, _, _ = oracle.run_qasm(path)
+    cumul = oracle.cumulative(want_state, n)
+    rng = np.random.default_rng(4)
+    draws = np.concatenate([rng.uniform(0, 1, 200), [0.0, 1e-300, 0.5, 1.0, 1.5]])
+    with Cluster(n, shards, devices=[0] * shards) as cl:
+        cl.run(Circuit.from_file(path))
+        ex, _ = cl.exchange_stats()
+        assert ex >= 1  # the map is not the identity any more
+        got = cl.sample(draws)
+    mism = 0
+    for r, g in zip(draws, got):
+        w = oracle.measure(cumul, n, float(r))
+        if int(g) != w:
+            assert abs(int(g) - w) == 1 and min(abs(cumul[w] - r), abs(cumul[int(g)] - r)) < 1e-13
+            mism += 1
+    assert mism <= 2
+    # CLI, sharded, behind QSIM_MEASURE
+    env = dict(os.environ, QSIM_MEASURE="1", QSIM_SHARDS=str(shards))
+    import re
+    p = subprocess.run([_lib.CLI_PATH, os.path.join(golden_dir, "grover_3_18.qasm"), "40"], capture_output=True, text=True, env=env)
+    lines = p.stdout.splitlines()
+    assert p.returncode == 0 and len(lines) == 41 and float(lines[0]) >= 0
+    hits = 0
+    for l in lines[1:]:
+        m = re.fullmatch(r"MEASUREMENT: ([01]{6}) \((\d+)\)", l)
+        assert m and int(m.group(1), 2) == int(m.group(2))
+        hits += int(m.group(2)) in (3, 18)
+    assert hits >= 25  # the two marked states carry ~99.9 % of the probability

@@ -290,6 +290,80 @@ class ShardedSimulator:
         self.dist.all_reduce(t)
         return complex(float(t[0]), float(t[1]))
 
+    def sample(self, randoms, block_bits: int = 12, chunk_bits: int = 22) -> np.ndarray:
+        """measurement() (quantum_simulator.c:270-283) on the sharded state, indices in LOGICAL order (collective: every
+        rank calls it with the same numbers and gets the same indices).  Each rank sums |a|^2 of its shard into the
+        logical 2^block_bits-amplitude blocks it holds a part of; ONE all-reduce adds the P partial sums per block
+        (SURVEY 8f row 1); a draw then needs the amplitudes of its own block only, contributed by their owners."""
+        import torch
+        dist, n, m = self.dist, self.n, self.m
+        pos = list(self.plan.final_pos)
+        inv = [0] * n  # physical bit -> logical qubit
+        for q, pq in enumerate(pos):
+            inv[pq] = q
+        bb = min(block_bits, n)
+        nblocks = 1 << (n - bb)
+        part = np.zeros(nblocks, dtype=np.float64)
+        piece = 1 << min(chunk_bits, m)
+        j = np.arange(piece, dtype=np.int64)
+        low = np.zeros(piece, dtype=np.int64)  # logical image of the physical bits inside a piece
+        for b in range(min(chunk_bits, m)):
+            low |= ((j >> b) & 1) << inv[b]
+        for at in range(0, 1 << m, piece):
+            hi = 0
+            phys_hi = (self.rank << m) | at
+            for b in range(min(chunk_bits, m), n):
+                hi |= ((phys_hi >> b) & 1) << inv[b]
+            a = self.shard.read(at, piece)
+            w = a.real * a.real + a.imag * a.imag
+            part += np.bincount((low | hi) >> bb, weights=w, minlength=nblocks)
+        cuda = dist.get_backend() == "nccl"
+        t = torch.from_numpy(part)
+        if cuda:
+            t = t.cuda()
+        dist.all_reduce(t)
+        prefix = np.cumsum(t.cpu().numpy())  # cumulative at the END of each block
+        r_all = np.ascontiguousarray(randoms, dtype=np.float64).reshape(-1)
+        out = np.zeros(r_all.size, dtype=np.uint64)
+        bsize = 1 << bb
+        cached, blk = -1, None
+        for k, rnd in enumerate(r_all):
+            lo, hi_ = 0, nblocks
+            while lo < hi_:  # first block whose end value is non-zero and >= r
+                mid = (lo + hi_) >> 1
+                if prefix[mid] == 0.0 or prefix[mid] < rnd:
+                    lo = mid + 1
+                else:
+                    hi_ = mid
+            idx, found, b = (1 << n) - 1, False, lo
+            while b < nblocks and not found:
+                if b != cached:
+                    logical = (b << bb) + np.arange(bsize, dtype=np.int64)
+                    phys = np.zeros(bsize, dtype=np.int64)
+                    for q, pq in enumerate(pos):
+                        phys |= ((logical >> q) & 1) << pq
+                    mine = np.nonzero((phys >> m) == self.rank)[0]
+                    buf = np.zeros(2 * bsize, dtype=np.float64)
+                    for i in mine:  # owners fill their slots; the sum over ranks is the block
+                        amp = self.shard.read(int(phys[i]) & ((1 << m) - 1), 1)[0]
+                        buf[2 * i], buf[2 * i + 1] = amp.real, amp.imag
+                    tb = torch.from_numpy(buf)
+                    if cuda:
+                        tb = tb.cuda()
+                    dist.all_reduce(tb)
+                    blk = tb.cpu().numpy()
+                    cached = b
+                cum = prefix[b - 1] if b else 0.0
+                probs = blk[0::2] * blk[0::2] + blk[1::2] * blk[1::2]
+                for i in range(bsize):
+                    cum += probs[i]
+                    if not (cum == 0.0 or cum < rnd):
+                        idx, found = (b << bb) + i, True
+                        break
+                b += 1
+            out[k] = idx
+        return out
+
     def close(self):
         self.shard.close()
 

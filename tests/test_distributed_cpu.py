@@ -104,7 +104,9 @@ def _worker(rank, world, port, n, gates, want, q):
         phys = torch.cat(shards).numpy().reshape(-1).view(np.complex128)
         got = logical_from_physical(phys, sim.plan.final_pos)
         err = float(np.max(np.abs(got - want)))
-        q.put((rank, err, norm, abs(amp5 - want[5]), sim.plan.exchanges, sim.exchange_bytes))
+        draws = np.concatenate([np.random.default_rng(7).uniform(0, 1, 40), [0.0, 1.0, 1.5]])
+        picked = sim.sample(draws, block_bits=4, chunk_bits=5)  # small blocks / pieces: several of each per shard
+        q.put((rank, err, norm, abs(amp5 - want[5]), sim.plan.exchanges, sim.exchange_bytes, draws, picked))
     finally:
         dist.destroy_process_group()
 
@@ -124,9 +126,15 @@ def test_gloo_ranks_equal_oracle(oracle, tmp_path, world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, err, norm, aerr, exchanges, xbytes in results:
+    cumul = oracle.cumulative(want, n)
+    for rank, err, norm, aerr, exchanges, xbytes, draws, picked in results:
         assert err < TOL and abs(norm - 1.0) < 1e-12 and aerr < TOL
         assert exchanges >= 1 and xbytes > 0
+        # the measurement post-path on the sharded state: same indices on every rank, equal to the oracle's search
+        assert np.array_equal(picked, results[0][7])
+        for r, g in zip(draws, picked):
+            w = oracle.measure(cumul, n, float(r))
+            assert int(g) == w or (abs(int(g) - w) == 1 and min(abs(cumul[w] - r), abs(cumul[int(g)] - r)) < 1e-13)
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])

@@ -362,6 +362,11 @@ def test_single_rank_process_group_bench_path(oracle, tmp_path):
         got = logical_from_physical(sim.shard.read_all(), sim.plan.final_pos)
         assert np.max(np.abs(got - want)) < TOL
         assert abs(sim.amplitude(7) - want[7]) < TOL
+        cumul = oracle.cumulative(want, n)  # the collective measurement post-path, here with one rank over RCCL
+        draws = np.random.default_rng(8).uniform(0, 1, 25)
+        for r, g in zip(draws, sim.sample(draws)):
+            w = oracle.measure(cumul, n, float(r))
+            assert int(g) == w or (abs(int(g) - w) == 1 and min(abs(cumul[w] - r), abs(cumul[int(g)] - r)) < 1e-13)
         sim.close()
     finally:
         dist.destroy_process_group()

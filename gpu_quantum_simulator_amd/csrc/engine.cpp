@@ -431,7 +431,7 @@ static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, int a
     for (int r = 0; r < D; r++) t.rowoff[r] = slot_off(r) << amp_shift;
     for (int v = 0; v < NB; v++)
         for (int r = 0; r < D; r++) {
-            const TileBlock::Row &row = blk.rows[v][r];
+            const TileBlock::Row &row = blk.row(v, r);
             int j = 0;
             for (; j < row.n; j++) {
                 const int e = r * T + j;
@@ -819,9 +819,8 @@ extern "C" int qsim_schedule_circuit(const qsim_circuit *c, int fuse, int tile_b
             double U[128];
             const int d = op.kind == OP_CX ? 0 : op.dim();
             for (int k = 0; k < d * d; k++) { U[2 * k] = op.m[k].real(); U[2 * k + 1] = op.m[k].imag(); }
-            const int kind = op.kind == OP_G1 ? QSIM_GATE_U1 : op.kind == OP_CX ? QSIM_GATE_CX
-                             : op.kind == OP_G2 ? QSIM_GATE_U2 : QSIM_GATE_U3;
-            const int qs[3] = {op.q_hi, op.q_lo, op.q_lo2};
+            const int kind = op.kind == OP_G1 ? QSIM_GATE_U1 : op.kind == OP_CX ? QSIM_GATE_CX : QSIM_GATE_U2;
+            const int qs[2] = {op.q_hi, op.q_lo};
             cb(user, pi, p.kclass, kind, qs, op.kind == OP_CX ? 2 : op.nq(), d ? U : nullptr, (int)op.gates);
         }
         for (const TileBlock &blk : p.blocks) { // reported as ONE matrix on (selecting qubits..., tile qubits...)

@@ -37,7 +37,7 @@ int FusedOp::max_row_nnz() const {
 uint64_t FusedOp::selector_mask() const {
     if (kind == OP_CX) return 1ULL << q_hi; // the control
     const int k = nq(), d = dim();
-    const int qs[3] = {q_hi, q_lo, q_lo2};
+    const int qs[2] = {q_hi, q_lo};
     uint64_t out = 0;
     for (int a = 0; a < k; a++) {
         const int bit = 1 << (k - 1 - a); // position of qs[a] in the row/column index
@@ -240,14 +240,14 @@ void Scheduler::finish(std::vector<Pass> &out) {
 int TileBlock::max_row_nnz() const {
     int best = 0;
     for (int v = 0; v < banks(); v++)
-        for (int r = 0; r < dim(); r++) best = std::max(best, rows[v][r].n);
+        for (int r = 0; r < dim(); r++) best = std::max(best, row(v, r).n);
     return best;
 }
 
 bool TileBlock::bank_is_identity(int v) const {
     for (int r = 0; r < dim(); r++) {
-        const Row &row = rows[v][r];
-        if (row.n != 1 || row.col[0] != r || !is_one(row.val[0])) return false;
+        const Row &rw = row(v, r);
+        if (rw.n != 1 || rw.col[0] != r || !is_one(rw.val[0])) return false;
     }
     return true;
 }
@@ -263,7 +263,7 @@ void TileBlock::full_matrix(cd *out) const {
     std::fill(out, out + (size_t)D * D, cd(0, 0));
     for (int v = 0; v < banks(); v++)
         for (int r = 0; r < d; r++)
-            for (int j = 0; j < rows[v][r].n; j++) out[(size_t)(v * d + r) * D + (v * d + rows[v][r].col[j])] = rows[v][r].val[j];
+            for (int j = 0; j < row(v, r).n; j++) out[(size_t)(v * d + r) * D + (v * d + row(v, r).col[j])] = row(v, r).val[j];
 }
 
 // Splits a fused op (1 or 2 qubits at level 3) by the tile: qubits in `inside` stay matrix indices, the others become
@@ -272,14 +272,15 @@ static TileBlock to_block(const FusedOp &op, uint64_t inside) {
     TileBlock t;
     t.gates = op.gates;
     const int k = op.nq(), D = op.dim();
-    const int qs[3] = {op.q_hi, op.q_lo, op.q_lo2};
-    int in_pos[3], sel_pos[3]; // bit positions (in the op's row index) of the inside / outside qubits, most significant first
+    const int qs[2] = {op.q_hi, op.q_lo};
+    int in_pos[2], sel_pos[2]; // bit positions (in the op's row index) of the inside / outside qubits, most significant first
     for (int a = 0; a < k; a++) {
         const int pos = k - 1 - a;
         if (inside >> qs[a] & 1ULL) { in_pos[t.nq] = pos; t.q[t.nq++] = qs[a]; }
         else { sel_pos[t.ns] = pos; t.s[t.ns++] = qs[a]; }
     }
     const int d = 1 << t.nq;
+    t.shape(t.nq, t.ns);
     auto compose = [&](int v, int r) { // op row index from bank index v and inside row index r
         int idx = 0;
         for (int a = 0; a < t.ns; a++) idx |= ((v >> (t.ns - 1 - a)) & 1) << sel_pos[a];
@@ -288,7 +289,7 @@ static TileBlock to_block(const FusedOp &op, uint64_t inside) {
     };
     for (int v = 0; v < (1 << t.ns); v++)
         for (int r = 0; r < d; r++) {
-            TileBlock::Row &row = t.rows[v][r];
+            TileBlock::Row &row = t.row(v, r);
             for (int c = 0; c < d; c++) {
                 const cd z = op.m[D * compose(v, r) + compose(v, c)];
                 if (!is_zero(z)) { row.col[row.n] = (uint8_t)c; row.val[row.n++] = z; } // d <= 4 = kMaxRowNnz
@@ -381,7 +382,7 @@ void Scheduler::tile_pass(const std::vector<FusedOp> &ops, uint64_t hset, const 
             if (sc.ns == tb.ns && sc.s[0] == tb.s[0] && sc.s[1] == tb.s[1]) {
                 for (int v = 0; v < tb.banks(); v++) { // 1x1 banks: the factors multiply
                     const cd z = tb.at(v, 0, 0) * sc.at(v, 0, 0);
-                    sc.rows[v][0].n = 1; sc.rows[v][0].col[0] = 0; sc.rows[v][0].val[0] = z;
+                    sc.row(v, 0).n = 1; sc.row(v, 0).col[0] = 0; sc.row(v, 0).val[0] = z;
                 }
                 sc.gates += tb.gates;
                 folded = true;
@@ -629,16 +630,18 @@ void Scheduler::merge_blocks(std::vector<TileBlock> &blocks) const {
     const int B = std::min(cfg_.tile_bits, cfg_.n);
     const int kMaxQ = B >= 11 ? std::min(cfg_.merge_qubits, kMaxBlockQ) : 3;
     constexpr int kMaxSel = 2;
-    std::vector<TileBlock> rem(blocks), next, out;
+    std::vector<int> rem(blocks.size()), next; // indices into `blocks`: the blocks themselves are moved, never copied
+    for (size_t i = 0; i < blocks.size(); i++) rem[i] = (int)i;
+    std::vector<TileBlock> out;
     TileBlock m;
     while (!rem.empty()) {
-        TileBlock cur = rem[0];
+        TileBlock cur = std::move(blocks[(size_t)rem[0]]);
         uint64_t blocked = 0;
         next.clear();
         for (size_t i = 1; i < rem.size(); i++) {
-            const TileBlock &op = rem[i];
+            const TileBlock &op = blocks[(size_t)rem[i]];
             const uint64_t qm = op.in_mask();
-            if (qm & blocked) { blocked |= qm; next.push_back(op); continue; }
+            if (qm & blocked) { blocked |= qm; next.push_back(rem[i]); continue; }
             const uint64_t un = cur.in_mask() | qm, us = cur.sel_mask() | op.sel_mask();
             bool merged = false;
             if (__builtin_popcountll(un) <= kMaxQ && __builtin_popcountll(us) <= kMaxSel) {
@@ -649,8 +652,7 @@ void Scheduler::merge_blocks(std::vector<TileBlock> &blocks) const {
                 }
                 const int D = 1 << k;
                 m = TileBlock();
-                m.nq = k;
-                m.ns = nss;
+                m.shape(k, nss);
                 for (int a = 0; a < k; a++) m.q[a] = qs[a];
                 for (int a = 0; a < nss; a++) m.s[a] = ss[a];
                 m.gates = cur.gates + op.gates;
@@ -661,10 +663,10 @@ void Scheduler::merge_blocks(std::vector<TileBlock> &blocks) const {
                     for (int r = 0; r < D && fits; r++) { // row r of (op after cur) = sum_t op[r][t] * cur[t][.]
                         int cols[kMaxRowNnz * kMaxRowNnz], n = 0;
                         cd vals[kMaxRowNnz * kMaxRowNnz];
-                        const TileBlock::Row &rb = op.rows[vb][eb.sub(op, r)];
+                        const TileBlock::Row &rb = op.row(vb, eb.sub(op, r));
                         for (int jb = 0; jb < rb.n; jb++) {
                             const int t = (r & ~eb.mask) | eb.spread(op, rb.col[jb]);
-                            const TileBlock::Row &ra = cur.rows[va][ea.sub(cur, t)];
+                            const TileBlock::Row &ra = cur.row(va, ea.sub(cur, t));
                             for (int ja = 0; ja < ra.n; ja++) {
                                 const int c = (t & ~ea.mask) | ea.spread(cur, ra.col[ja]);
                                 const cd z = rb.val[jb] * ra.val[ja];
@@ -674,7 +676,7 @@ void Scheduler::merge_blocks(std::vector<TileBlock> &blocks) const {
                                 else vals[e] += z;
                             }
                         }
-                        TileBlock::Row &row = m.rows[v][r];
+                        TileBlock::Row &row = m.row(v, r);
                         row.n = 0;
                         for (int e = 0; e < n; e++) {
                             if (is_zero(vals[e])) continue; // exact cancellation
@@ -689,20 +691,20 @@ void Scheduler::merge_blocks(std::vector<TileBlock> &blocks) const {
                 if (fits) {
                     for (int v = 0; v < (1 << nss); v++) // keep every row's entries in ascending column order
                         for (int r = 0; r < D; r++) {
-                            TileBlock::Row &row = m.rows[v][r];
+                            TileBlock::Row &row = m.row(v, r);
                             for (int x = 1; x < row.n; x++)
                                 for (int y = x; y > 0 && row.col[y - 1] > row.col[y]; y--) {
                                     std::swap(row.col[y - 1], row.col[y]);
                                     std::swap(row.val[y - 1], row.val[y]);
                                 }
                         }
-                    cur = m;
+                    std::swap(cur, m);
                     merged = true;
                 }
             }
-            if (!merged) { blocked |= qm; next.push_back(op); }
+            if (!merged) { blocked |= qm; next.push_back(rem[i]); }
         }
-        if (!cur.is_identity()) out.push_back(cur);
+        if (!cur.is_identity()) out.push_back(std::move(cur));
         rem.swap(next);
     }
     blocks.swap(out);

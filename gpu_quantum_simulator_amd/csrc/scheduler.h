@@ -21,22 +21,20 @@ namespace qsim {
 
 using cd = std::complex<double>;
 
-enum OpKind : int { OP_G1 = 1, OP_CX = 2, OP_G2 = 3, OP_G3 = 4 };
+enum OpKind : int { OP_G1 = 1, OP_CX = 2, OP_G2 = 3 };
 
 struct FusedOp {
     int kind = 0;
-    int q_hi = -1;  // OP_G1: target; OP_CX: control; OP_G2/OP_G3: highest qubit
-    int q_lo = -1;  // OP_CX: target; OP_G2: low qubit; OP_G3: middle qubit
-    int q_lo2 = -1; // OP_G3: lowest qubit
-    cd m[64];       // row-major 2x2 / 4x4 / 8x8; index bits = (q_hi, q_lo[, q_lo2]), most significant first
+    int q_hi = -1;  // OP_G1: target; OP_CX: control; OP_G2: high qubit
+    int q_lo = -1;  // OP_CX: target; OP_G2: low qubit
+    cd m[16];       // row-major 2x2 / 4x4; index bits = (q_hi[, q_lo]), most significant first
     uint32_t gates = 0;
 
-    int nq() const { return kind == OP_G1 ? 1 : kind == OP_G3 ? 3 : 2; }
+    int nq() const { return kind == OP_G1 ? 1 : 2; }
     int dim() const { return 1 << nq(); }
     uint64_t qmask() const {
         uint64_t m = 1ULL << q_hi;
         if (kind != OP_G1) m |= 1ULL << q_lo;
-        if (kind == OP_G3) m |= 1ULL << q_lo2;
         return m;
     }
     int max_row_nnz() const; // exact-zero structure
@@ -61,17 +59,21 @@ struct TileBlock {
         uint8_t col[kMaxRowNnz];
         cd val[kMaxRowNnz];
     };
-    Row rows[kMaxBanks][1 << kMaxBlockQ];
+    std::vector<Row> store; // banks() x dim() rows, bank-major; sized by shape()
     uint32_t gates = 0;
+
+    void shape(int nq_, int ns_) { nq = nq_; ns = ns_; store.assign((size_t)1 << (nq_ + ns_), Row()); }
+    Row &row(int v, int r) { return store[((size_t)v << nq) + r]; }
+    const Row &row(int v, int r) const { return store[((size_t)v << nq) + r]; }
 
     int dim() const { return 1 << nq; }
     int banks() const { return 1 << ns; }
     uint64_t in_mask() const { uint64_t m = 0; for (int a = 0; a < nq; a++) m |= 1ULL << q[a]; return m; }
     uint64_t sel_mask() const { uint64_t m = 0; for (int a = 0; a < ns; a++) m |= 1ULL << s[a]; return m; }
     cd at(int v, int r, int c) const {
-        const Row &row = rows[v][r];
-        for (int j = 0; j < row.n; j++)
-            if (row.col[j] == c) return row.val[j];
+        const Row &rw = row(v, r);
+        for (int j = 0; j < rw.n; j++)
+            if (rw.col[j] == c) return rw.val[j];
         return cd(0, 0);
     }
     int max_row_nnz() const;    // over all banks

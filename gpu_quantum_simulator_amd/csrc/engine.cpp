@@ -421,12 +421,14 @@ static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, int a
     t.kind = TOP_SP;
     t.terms = T;
     // LDS BYTE offset of a slot code (bit a of the code sits at tile-local bit b[a]), already passed through the
-    // kernel's layout swizzle (kernels_impl.inc sw_slot: unit bits 0..3 ^= slot bit 4; linear, so it commutes with the
-    // XOR the kernel combines it with)
+    // kernel's layout swizzle (kernels_impl.inc sw_slot: unit bits 0..3 ^= a linear image of the higher slot bits;
+    // linear, so it commutes with the XOR the kernel combines it with)
     auto slot_off = [&](int code) {
         uint32_t o = 0;
         for (int a = 0; a < k; a++) o |= (uint32_t)((code >> a) & 1) << t.b[a];
-        return o ^ (((o >> 4) & 1u) * 15u);
+        const uint32_t hi = o >> 4, f = (hi ^ (hi >> 5) ^ (hi >> 10)) & 31u; // = sw_fold of kernels_impl.inc
+        if (amp_shift == 3) return o ^ ((0u - (hi & 1u)) & 15u);            // fp32 states keep the bit-4-only swizzle
+        return o ^ (((f >> 1) & 15u) ^ ((0u - (f & 1u)) & 15u));
     };
     for (int r = 0; r < D; r++) t.rowoff[r] = slot_off(r) << amp_shift;
     for (int v = 0; v < NB; v++)

@@ -2,25 +2,28 @@
 """bench.py — BASELINE.json's metric on its config: gate-applies/s (+ achieved HBM GB/s) for a seeded
 random circuit, n = 30 qubits fp64, 1000 gate statements (configs[3]; fits one MI355X: 16 GiB state).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = the whole circuit applied to a fresh |0...0> (init kernel + every fused pass), inputs
-resident in HBM (the gate list is parsed once, before the timed region).  N > 1 shards the SAME 2^30
-state over N ranks (strong scaling; top log2 N qubits global, exchanged over RCCL) — see
-gpu_quantum_simulator_amd/distributed.py.
+One "step" = the whole circuit applied to a fresh |0...0> (init + every fused pass), inputs resident in HBM (the
+gate list is parsed once, before the timed region).  N > 1 shards the SAME 2^n state over N ranks, one process per
+GPU (strong scaling; top log2 N qubits global, exchanged with RCCL send/recv) — gpu_quantum_simulator_amd/distributed.py.
 
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
-  roofline     — dominant kernel class: algorithmic bytes / HIP-event time measured live on the engine's
-                 stream during the timed steps, against the 8 TB/s HBM3E peak;
-  cpu_baseline — the reference's own loops (oracle/_ref, kind "reference") or the restatement
-                 (oracle/liboracle.so, kind "port") timed on this host, 1 thread, on the first few
-                 gates of the same circuit (bounded to ~15 s).
+  roofline     — dominant kernel class: algorithmic bytes / HIP-event time measured live on the engine's own
+                 stream during the timed steps, against the 8 TB/s HBM3E peak; `traffic` = PMC bytes per launch
+                 from the committed rocprofv3 summary of this same command (`traffic_source` names it);
+  cpu_baseline — the CPU restatement of quantum_simulator.c's loops (oracle/liboracle.so, kind "port",
+                 byte-identical to the compiled reference in the container tests) timed on this host,
+                 1 thread, on the first gates of the same circuit (bounded to ~12 s); N = 1 only;
+  sizes        — the same measurement at n = 24, 28, 32 (north_star / tester.bash:5-48 protocol): gate-applies/s,
+                 the tile kernel's GB/s and fraction of peak, and a bounded CPU sample beside each (N = 1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -32,7 +35,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -55,9 +58,12 @@ def parse_args():
     ap.add_argument("--precision", type=int, default=64, choices=[64, 32],
                     help="64 = the headline / parity configuration; 32 = fp32 state like the reference's CUDA variants "
                          "(an extra measurement, single GPU only, reported with dtype f32)")
+    ap.add_argument("--sizes", default="24,28,32",
+                    help="other register sizes measured after the headline run and reported under `sizes` ('' = none)")
+    ap.add_argument("--size-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 KERNEL_SYMBOL = {"tile": "k_tile<12, 512>", "gate1": "k_gate1_hi<4, false>",
@@ -65,202 +71,281 @@ KERNEL_SYMBOL = {"tile": "k_tile<12, 512>", "gate1": "k_gate1_hi<4, false>",
 
 
 def pmc_traffic(kernel_class, is_default_workload):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this same
-    command (profiles/rNN/bench_n30_pmc_summary.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes).
-    Counters cannot be read from inside the process, so this is null for any other workload."""
+    """(HBM bytes per launch of the dominant kernel, source file) from the committed rocprofv3 --pmc summary of this
+    same command (profiles/rNN/bench_n30_pmc_summary.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes).
+    Counters cannot be read from inside the process, so this is (None, None) for any other workload; the summary must
+    be refreshed in the commit that changes the kernel — `traffic_source` says which profile the number is from."""
     if not is_default_workload:
-        return None
+        return None, None
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_n30_pmc_summary.json")))
     if not files:
-        return None
+        return None, None
     with open(files[-1]) as f:
         summary = json.load(f)
     want = KERNEL_SYMBOL.get(kernel_class)
     for name, entry in summary.get("kernels", {}).items():
         if want and name.endswith("::" + want) and "f32" not in name:
-            return entry["hbm_traffic_bytes_per_launch"]
-    return None
+            return entry["hbm_traffic_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
+def host_ram_bytes():
+    try:
+        return os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
+    except (ValueError, OSError):
+        return 0
 
 
 def cpu_baseline(n, gates, budget_s):
-    """The reference's hot loops on this host's cores (1 thread), bounded sample of the same circuit."""
+    """quantum_simulator.c's hot loops (the oracle's restatement of :81-106) on this host, 1 thread, on a bounded
+    sample of the same circuit."""
     import ctypes
 
     import numpy as np
     from oracle import oracle  # the checker, used here only as the timed CPU baseline
 
+    need = 16 << n
+    if need + (8 << 30) > host_ram_bytes():
+        return {"value": None, "unit": "gate-applies/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
+                "sample": f"not run: the 2^{n} state ({need >> 30} GiB) does not fit this host's RAM"}
     oracle.build(with_reference=False)
-    use_ref = oracle.have_reference()
     dp = ctypes.POINTER(ctypes.c_double)
     state = np.zeros(1 << n, dtype=np.complex128)
     state[0] = 1.0
     state[1:] = 0.0  # touch every page before the clock starts
     sp = state.view(np.float64).ctypes.data_as(dp)
     from gpu_quantum_simulator_amd import gate_matrix
-    if use_ref:
-        R = oracle.reference_lib()
-        one_q = lambda u, q: R.execute_single_qubit_gate(sp, n, u.view(np.float64).ctypes.data_as(dp), q)
-        cx = lambda c, t: R.execute_cnot(sp, n, c, t)
-    else:
-        L = oracle.lib()
-        one_q = lambda u, q: L.oracle_apply_1q(sp, n, u.view(np.float64).ctypes.data_as(dp), q)
-        cx = lambda c, t: L.oracle_apply_cx(sp, n, c, t)
+    L = oracle.lib()
     done = 0
     t0 = time.perf_counter()
     for g in gates:
         if g[0] == "cx":
-            cx(g[1], g[2])
+            L.oracle_apply_cx(sp, n, g[1], g[2])
         else:
             tok = f"rz({g[1]!r})" if g[0] == "rz" else g[0]
             u = np.ascontiguousarray(gate_matrix(tok).T.reshape(4))  # symmetric anyway (SURVEY S7)
-            one_q(u, g[-1])
+            L.oracle_apply_1q(sp, n, u.view(np.float64).ctypes.data_as(dp), g[-1])
         done += 1
         if time.perf_counter() - t0 >= budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "gate-applies/s", "cores": 1, "host_cores": os.cpu_count(),
-            "kind": "reference" if use_ref else "port",
-            "sample": f"first {done} gate statements of the same n={n} circuit, {dt:.1f} s, state resident in host RAM"}
+    del state
+    return {"value": done / dt, "unit": "gate-applies/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
+            "sample": f"first {done} gate statements of the same n={n} circuit, {dt:.1f} s, 1 thread, state resident in host RAM"}
+
+
+def launch_ranks(args):
+    """--gpus N > 1 without a launcher: become the parent of N rank processes.  Nothing here touches the GPU."""
+    from gpu_quantum_simulator_amd import launch
+    present = launch.count_gpus()
+    if present is not None and present < args.gpus:
+        sys.stderr.write(f"bench.py: {args.gpus} GPUs requested, {present} present\n")
+        return 2
+    rc, out = launch.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+    for ln in out.splitlines():
+        if ln not in lines:
+            sys.stderr.write(ln + "\n")
+    if lines:
+        print(lines[-1], flush=True)
+    elif rc == 0:
+        rc = 1
+    return rc
+
+
+class Bench:
+    def __init__(self, args):
+        self.args = args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+
+    def setup(self):
+        import torch
+        args = self.args
+        ndev = torch.cuda.device_count()  # does not initialise the GPU on this image
+        if ndev < max(args.gpus, 1) or self.local_rank >= ndev:
+            sys.stderr.write(f"bench.py: {args.gpus} GPUs requested, {ndev} present\n")
+            sys.exit(2)
+        torch.cuda.set_device(self.local_rank)
+        if self.world > 1 or args.force_sharded:
+            import torch.distributed as dist
+            if "MASTER_ADDR" not in os.environ:
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            self.dist = dist
+        self.torch = torch
+
+    def fence(self, sim):
+        sim.sync()
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def measure(self, n, depth, vocabulary, seed, steps, warmup, fuse, opts, probe_q=None, with_1q_probe=False):
+        """Builds the simulator for one register size, runs `warmup` + `steps` timed steps, returns the numbers."""
+        from gpu_quantum_simulator_amd import Circuit, Simulator, circuits
+        args, dist, torch = self.args, self.dist, self.torch
+        if probe_q is not None:
+            gates = circuits.probe_gates(n, probe_q, depth)
+            fuse = 0
+            workload = f"single-qubit probe: {depth} x h q[{probe_q}], n={n}, fusion off"
+        else:
+            gates = circuits.random_gates(n, depth, seed, vocabulary)
+            workload = f"random circuit ({vocabulary}), n={n}, depth {depth}, seed {seed}"
+        if dist is not None:
+            from gpu_quantum_simulator_amd.distributed import ShardedSimulator
+            sim = ShardedSimulator(n, gates, device=self.local_rank, fuse=fuse, profile=True, **opts)
+            run_step = sim.run_step
+        else:
+            circuit = Circuit.from_gates(n, gates)
+            sim = Simulator(n, self.local_rank, fuse=fuse, profile=True, precision=args.precision, **opts)
+
+            def run_step():
+                sim.reset()
+                sim.run(circuit)
+                sim.flush()
+
+        for _ in range(warmup):
+            run_step()
+        self.fence(sim)
+        sim.reset_stats()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run_step()
+        self.fence(sim)
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        stats = sim.stats()
+        norm2 = sim.norm2()
+
+        # north_star target "single-qubit gate apply at n=30": a short dense-1q probe on the same (now dense) state
+        probe = None
+        if with_1q_probe and dist is None and probe_q is None and n >= 8:
+            from gpu_quantum_simulator_amd import _lib as _qlib, gate_matrix
+            H = gate_matrix("h")
+            sim.set_option(_qlib.OPT_FUSE, 0)  # one launch per gate on the live (dense, random) state; H^6 = I
+            probe = {}
+            for q in sorted({0, min(12, n - 1), n - 1}):
+                sim.sync()
+                sim.reset_stats()
+                for _ in range(6):
+                    sim.apply_1q(H, q)
+                sim.sync()
+                k = {kk: vv for kk, vv in sim.stats()["kernels"].items() if vv["launches"] and kk != "init"}
+                name = next(iter(k))
+                gbs = k[name]["bytes"] / (k[name]["ms"] * 1e-3) / 1e9
+                probe[f"q{q}"] = {"kernel": name, "achieved": gbs, "frac": gbs / HBM_PEAK_GBPS, "avg_launch_ms": k[name]["ms"] / 6}
+
+        res = {"workload": workload, "n": n, "gates": gates, "elapsed": elapsed, "steps": steps, "stats": stats,
+               "norm2": norm2, "probe": probe, "fuse": fuse}
+        if dist is not None:
+            xs, xb = sim.exchange_seconds / steps, sim.exchange_bytes / steps
+            res["exchange"] = {"per_step": sim.plan.exchanges,
+                               "qubits_swapped": [len(s[1]) for s in sim.plan.steps if s[0] == "exchange"],
+                               "bytes_sent_per_rank_per_step": xb, "seconds_per_step": xs,
+                               "xgmi_gbps_per_rank": (xb / xs / 1e9) if xs > 0 else None,
+                               "predicted": getattr(sim, "exchange_prediction", None),
+                               "note": "seconds: pack + send/recv as seen by rank 0's host clock"}
+        sim.close()
+        del sim
+        return res
+
+    @staticmethod
+    def roofline_of(stats):
+        kernels = {k: v for k, v in stats["kernels"].items() if v["launches"] and k != "init"}
+        dom = max(kernels, key=lambda k: kernels[k]["ms"]) if kernels else None
+        if not dom or kernels[dom]["ms"] <= 0:
+            return None
+        achieved = kernels[dom]["bytes"] / (kernels[dom]["ms"] * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "launches": kernels[dom]["launches"],
+                "avg_launch_ms": kernels[dom]["ms"] / kernels[dom]["launches"],
+                "algorithmic_bytes_per_launch": kernels[dom]["bytes"] / kernels[dom]["launches"]}
 
 
 def main():
     args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with python -m torch.distributed.run "
-                     f"--nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...")
-        sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    b = Bench(args)
+    if b.world != args.gpus:
+        sys.exit(f"WORLD_SIZE={b.world} does not match --gpus {args.gpus}")
+    if args.precision == 32 and (b.world > 1 or args.force_sharded):
+        sys.exit("--precision 32 is single-GPU only (shards and clusters are fp64)")
+    b.setup()
 
-    import numpy as np
-    import torch
-
-    from gpu_quantum_simulator_amd import Circuit, Simulator, circuits
-
-    n = args.qubits + (int(round(__import__("math").log2(world))) if args.scaling == "weak" else 0)
+    n = args.qubits + (int(round(math.log2(b.world))) if args.scaling == "weak" else 0)
     seed = args.seed if args.seed is not None else 20240117 + n
-    if args.probe is not None:
-        gates = circuits.probe_gates(n, args.probe, args.depth)
-        fuse = 0
-        workload = f"single-qubit probe: {args.depth} x h q[{args.probe}], n={n}, fusion off"
-    else:
-        gates = circuits.random_gates(n, args.depth, seed, args.vocabulary)
-        fuse = args.fuse
-        workload = f"random circuit ({args.vocabulary}), n={n}, depth {args.depth}, seed {seed}"
     opts = {k: v for k, v in (("tile_bits", args.tile_bits), ("tile_low_bits", args.tile_low_bits),
                               ("tile_max_ops", args.tile_max_ops), ("grid_cap", args.grid_cap)) if v is not None}
+    head = b.measure(n, args.depth, args.vocabulary, seed, args.steps, args.warmup, args.fuse, opts,
+                     probe_q=args.probe, with_1q_probe=True)
 
-    dist = None
-    if args.precision == 32 and (world > 1 or args.force_sharded):
-        sys.exit("--precision 32 is single-GPU only (shards and clusters are fp64)")
-    if world > 1 or args.force_sharded:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        from gpu_quantum_simulator_amd.distributed import ShardedSimulator
-        sim = ShardedSimulator(n, gates, device=local_rank, fuse=fuse, profile=True, **opts)
-        run_step = sim.run_step
-    else:
-        torch.cuda.set_device(local_rank)
-        circuit = Circuit.from_gates(n, gates)
-        sim = Simulator(n, local_rank, fuse=fuse, profile=True, precision=args.precision, **opts)
+    # other register sizes, same generator and defaults (north_star: n = 24/28/30/32)
+    sizes = []
+    if args.sizes and args.probe is None and args.precision == 64:
+        for m in [int(x) for x in args.sizes.split(",") if x.strip()]:
+            if m == n or m - int(round(math.log2(b.world))) < 14:
+                continue
+            r = b.measure(m, args.depth, args.vocabulary, 20240117 + m, args.size_steps, 1, args.fuse, opts)
+            sizes.append(r)
 
-        def run_step():
-            sim.reset()
-            sim.run(circuit)
-            sim.flush()
-
-    def fence():
-        sim.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        run_step()
-    fence()
-    sim.reset_stats()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    stats = sim.stats()
-    norm2 = sim.norm2()
-
-    # north_star target "single-qubit gate apply at n=30": a short dense-1q probe on the same (now dense) state
-    probe = None
-    if dist is None and args.probe is None and n >= 8:
-        from gpu_quantum_simulator_amd import _lib as _qlib, gate_matrix
-        H = gate_matrix("h")
-        sim.set_option(_qlib.OPT_FUSE, 0)  # one launch per gate on the live (dense, random) state; H^6 = I
-        probe = {}
-        for q in sorted({0, min(12, n - 1), n - 1}):
-            sim.sync()
-            sim.reset_stats()
-            for _ in range(6):
-                sim.apply_1q(H, q)
-            sim.sync()
-            k = {kk: vv for kk, vv in sim.stats()["kernels"].items() if vv["launches"] and kk != "init"}
-            name = next(iter(k))
-            gbs = k[name]["bytes"] / (k[name]["ms"] * 1e-3) / 1e9
-            probe[f"q{q}"] = {"kernel": name, "achieved": gbs, "frac": gbs / HBM_PEAK_GBPS, "avg_launch_ms": k[name]["ms"] / 6}
-        sim.set_option(_qlib.OPT_FUSE, fuse)
-
-    if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = args.depth * args.steps / elapsed
-        kernels = {k: v for k, v in stats["kernels"].items() if v["launches"] and k != "init"}
-        dom = max(kernels, key=lambda k: kernels[k]["ms"]) if kernels else None
-        roof = None
-        if dom and kernels[dom]["ms"] > 0:
-            achieved = kernels[dom]["bytes"] / (kernels[dom]["ms"] * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS,
-                    "traffic": pmc_traffic(dom, args.precision == 64 and args.probe is None and n == 30 and args.depth == 1000 and fuse == 3
-                                           and args.gpus == 1 and not opts and args.vocabulary == "all"),
-                    "launches": kernels[dom]["launches"],
-                    "avg_launch_ms": kernels[dom]["ms"] / kernels[dom]["launches"],
-                    "algorithmic_bytes_per_launch": kernels[dom]["bytes"] / kernels[dom]["launches"]}
+    if b.rank == 0:
+        stats = head["stats"]
+        ms_per_step = 1e3 * head["elapsed"] / args.steps
+        value = args.depth * args.steps / head["elapsed"]
+        roof = Bench.roofline_of(stats)
+        if roof:
+            default = (args.precision == 64 and args.probe is None and n == 30 and args.depth == 1000 and head["fuse"] == 3
+                       and args.gpus == 1 and not opts and args.vocabulary == "all")
+            roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"], default)
         total_kernel_ms = sum(v["ms"] for v in stats["kernels"].values())
         out = {
             "metric": "gate-applies/sec", "value": value, "unit": "gate-applies/s", "n_gpus": args.gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
-            "config": {"workload": workload, "qubits": n, "gate_statements": args.depth, "fuse": fuse,
+            "config": {"workload": head["workload"], "qubits": n, "gate_statements": args.depth, "fuse": head["fuse"],
                        "state_bytes": (16 if args.precision == 64 else 8) * (1 << n), "parallelism": f"shard{args.gpus}", **opts},
+            "n_ranks_seen": b.dist.get_world_size() if b.dist is not None else 1,
             "hbm_gbps_all_kernels": stats["algorithmic_bytes"] / (total_kernel_ms * 1e-3) / 1e9 if total_kernel_ms else None,
             "launches_per_step": stats["launches"] / args.steps,
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in stats["kernels"].items() if v["launches"]},
-            "norm2": norm2,
+            "norm2": head["norm2"],
             "roofline": roof,
-            "roofline_1q_probe": probe,
+            "roofline_1q_probe": head["probe"],
         }
-        if dist is not None:
-            xs = sim.exchange_seconds / args.steps
-            xb = sim.exchange_bytes / args.steps
-            out["exchange"] = {"per_step": sim.plan.exchanges, "qubits_swapped": [len(s[1]) for s in sim.plan.steps if s[0] == "exchange"],
-                               "bytes_sent_per_rank_per_step": xb, "seconds_per_step": xs,
-                               "xgmi_gbps_per_rank": (xb / xs / 1e9) if xs > 0 else None,
-                               "note": "seconds include the pack kernel and host-side stream hand-offs (rank 0's clock)"}
-        if not args.no_cpu_baseline and args.gpus == 1:
-            out["cpu_baseline"] = cpu_baseline(n, gates, args.cpu_seconds)
+        if "exchange" in head:
+            out["exchange"] = head["exchange"]
+        cpu = not args.no_cpu_baseline and args.gpus == 1 and b.dist is None
+        if cpu:
+            out["cpu_baseline"] = cpu_baseline(n, head["gates"], args.cpu_seconds)
+        if sizes:
+            table = []
+            for r in sizes:
+                rf = Bench.roofline_of(r["stats"])
+                row = {"qubits": r["n"], "state_bytes": 16 << r["n"], "workload": r["workload"],
+                       "value": args.depth * r["steps"] / r["elapsed"], "unit": "gate-applies/s",
+                       "ms_per_step": 1e3 * r["elapsed"] / r["steps"], "steps": r["steps"],
+                       "launches_per_step": r["stats"]["launches"] / r["steps"], "norm2": r["norm2"],
+                       "roofline": None if rf is None else {k: rf[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms")}}
+                if "exchange" in r:
+                    row["exchange"] = r["exchange"]
+                if cpu:
+                    # ~10 s of CPU work per size: about 170 gates at n=24, 10 at n=28, 1 at n=32 (one gate there takes longer)
+                    row["cpu_baseline"] = cpu_baseline(r["n"], r["gates"], 10.0 if r["n"] < 31 else 1.0)
+                table.append(row)
+            out["sizes"] = table
         print(json.dumps(out), flush=True)
-    sim.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if b.dist is not None:
+        b.dist.barrier()
+        b.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

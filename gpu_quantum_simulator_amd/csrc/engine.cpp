@@ -152,7 +152,14 @@ extern "C" void qsim_destroy(qsim_state *s) {
 }
 
 extern "C" int qsim_num_qubits(const qsim_state *s) { return s ? s->n : -1; }
-extern "C" void *qsim_device_ptr(qsim_state *s) { return s ? s->amps : nullptr; }
+static int materialize_zero_ket(qsim_state *s);
+// The buffer as every queued gate left it: pending gates are launched and a lazily held |0...0> is written first (the
+// work is ON the state's stream, not finished: order later accesses after qsim_stream() or call qsim_sync).
+extern "C" void *qsim_device_ptr(qsim_state *s) {
+    if (!s) return nullptr;
+    if (qsim_flush(s) != QSIM_OK || materialize_zero_ket(s) != QSIM_OK) return nullptr;
+    return s->amps;
+}
 extern "C" void *qsim_stream(qsim_state *s) { return s ? (void *)s->stream : nullptr; }
 
 extern "C" int qsim_set_option(qsim_state *s, int option, long value) {

@@ -53,8 +53,22 @@ static int dump_text(qsim_state *s, const char *path) {
 static int run_sharded(qsim_circuit *c, int shards, double t_start, long shots) {
     qsim_cluster *cl = NULL;
     const char *v;
-    int rc = qsim_cluster_create(&cl, qsim_circuit_num_qubits(c), shards, NULL);
-    if (rc == QSIM_OK && (v = getenv("QSIM_FUSE")) && *v) rc = qsim_cluster_set_option(cl, QSIM_OPT_FUSE, atol(v));
+    if ((v = getenv("QSIM_PRECISION")) && atoi(v) == 32) { /* shards are fp64 only: say so instead of running fp64 silently */
+        printf("ERROR: QSIM_PRECISION=32 is not supported together with QSIM_SHARDS (sharded states are fp64)\n");
+        printf("ERROR while parsing quantum circuit\n");
+        exit(1);
+    }
+    int ndev = qsim_device_count(), first_dev = (v = getenv("QSIM_DEVICE")) && *v ? atoi(v) : 0;
+    int *devices = (int *)malloc((size_t)shards * sizeof(int)); /* round-robin over the visible GPUs, starting at QSIM_DEVICE */
+    for (int r = 0; devices && r < shards; r++) devices[r] = ndev > 0 ? (first_dev + r) % ndev : 0;
+    int rc = devices ? qsim_cluster_create(&cl, qsim_circuit_num_qubits(c), shards, devices) : QSIM_ERR_ALLOC;
+    free(devices);
+    static const struct { const char *env; int opt; } fwd[] = {
+        {"QSIM_FUSE", QSIM_OPT_FUSE}, {"QSIM_TILE_BITS", QSIM_OPT_TILE_BITS}, {"QSIM_TILE_LOW_BITS", QSIM_OPT_TILE_LOW_BITS},
+        {"QSIM_TILE_MAX_OPS", QSIM_OPT_TILE_MAX_OPS}, {"QSIM_GRID_CAP", QSIM_OPT_GRID_CAP}, {"QSIM_PROFILE", QSIM_OPT_PROFILE},
+        {"QSIM_TILE_THREADS", QSIM_OPT_TILE_THREADS}};
+    for (size_t i = 0; rc == QSIM_OK && i < sizeof fwd / sizeof fwd[0]; i++)
+        if ((v = getenv(fwd[i].env)) && *v) rc = qsim_cluster_set_option(cl, fwd[i].opt, atol(v));
     if (rc == QSIM_OK) rc = qsim_cluster_reset(cl);
     if (rc == QSIM_OK) rc = qsim_cluster_run_circuit(cl, c);
     if (rc == QSIM_OK) rc = qsim_cluster_sync(cl);
@@ -158,15 +172,20 @@ int main(int argc, char *argv[]) {
         const int nq = qsim_num_qubits(s);
         srand((unsigned)time(NULL)); /* RAND PRE-HEAT, :45-47 */
         for (int i = 0; i < 10; i++) rand();
+        /* all draws first (same rand() order as the reference's loop, :67-73), then ONE pass over the state */
         char *bits = (char *)malloc((size_t)nq + 1);
-        for (long m = 0; m < shots && bits; m++) {
-            const double r = qsim_draw_randn();
-            uint64_t idx = 0;
-            if (qsim_sample(s, &r, 1, &idx) != QSIM_OK) { fprintf(stderr, "qsim: %s\n", qsim_last_error()); break; }
-            qsim_putb((long long)idx, nq, bits);
-            printf("MEASUREMENT: %s (%llu)\n", bits, (unsigned long long)idx);
+        double *r = (double *)malloc((size_t)(shots > 0 ? shots : 1) * sizeof(double));
+        uint64_t *idx = (uint64_t *)malloc((size_t)(shots > 0 ? shots : 1) * sizeof(uint64_t));
+        for (long m = 0; r && m < shots; m++) r[m] = qsim_draw_randn();
+        if (bits && r && idx && shots > 0 && qsim_sample(s, r, shots, idx) == QSIM_OK) {
+            for (long m = 0; m < shots; m++) {
+                qsim_putb((long long)idx[m], nq, bits);
+                printf("MEASUREMENT: %s (%llu)\n", bits, (unsigned long long)idx[m]);
+            }
+        } else if (shots > 0) {
+            fprintf(stderr, "qsim: %s\n", qsim_last_error());
         }
-        free(bits);
+        free(bits); free(r); free(idx);
     }
     if ((v = getenv("QSIM_DUMP")) && *v && qsim_dump_raw(s, v) != QSIM_OK) fprintf(stderr, "qsim: dump failed: %s\n", qsim_last_error());
     if ((v = getenv("QSIM_DUMP_TEXT")) && *v && dump_text(s, v) != QSIM_OK) fprintf(stderr, "qsim: dump failed: %s\n", qsim_last_error());

@@ -16,8 +16,17 @@
  * Also accepted: the CUDA variants' `<num_qubit> <num_gates>` form, detected by a leading digit
  * (quantum_simulator_naive.cu:239-240, gate lines :258-397).
  *
- * Where the reference has undefined behaviour this front-end reports an error instead: operand outside
- * [0, n), gate before the `qubit` statement, `rz` without a readable angle.
+ * Two corners of that loop are reproduced on purpose (tests/test_scheduler_cpu.py pins both against the oracle):
+ *   - a second `qubit` statement allocates a fresh |0...0> of the new size (:162-181), so every gate read before it
+ *     has no effect: the gate list is emptied;
+ *   - a file whose LAST statement is `qubit ...` followed by at least one more character (the usual final newline)
+ *     fails with "Unknown token: <that character>": the skip to the end of the line (:179-180) stops at '\n' without
+ *     raising end-of-file, so the statement loop runs once more and takes the blank as a gate name (:147-151).
+ *     Without any character after the line the same file is accepted and yields |0...0>.
+ *
+ * Deliberate deviations — where the reference has undefined behaviour this front-end reports an error instead:
+ * operand outside [0, n), gate before the `qubit` statement, `rz` without a readable angle, and a file without any
+ * `qubit` statement (the reference prints its time line and returns the NULL vector, :125,:248-252).
  */
 #include <ctype.h>
 #include <math.h>
@@ -182,12 +191,19 @@ static void seek_operand(cursor *s) {
 }
 
 /* statement loop shared by both file forms; max_gates < 0 = until end of input */
-static int parse_statements(cursor *s, qsim_circuit *c, int have_register, long max_gates) {
+static int parse_statements(cursor *s, qsim_circuit *c, int *have_reg, long max_gates) {
+    int have_register = *have_reg;
     while (!s->eof && (max_gates < 0 || c->count < max_gates)) {
         char tok[TOKEN_MAX + 1];
         int tl = 0;
         while (separator(s->c, 0) && !s->eof) advance(s);
-        if (s->eof && separator(s->c, 0)) break; /* only blanks were left (the reference would report them as a token) */
+        if (s->eof && separator(s->c, 0)) {
+            /* Only blanks were left.  The reference takes the last one as a gate name (:147-151); in the OPENQASM form
+             * that can only happen right after a `qubit` line (after a gate the trailing blanks are consumed by
+             * :240-242, which raises end-of-file before the loop test). */
+            if (max_gates < 0) { qsim_set_circuit_error("Unknown token: %c", s->c); return QSIM_ERR_PARSE; }
+            break;
+        }
         tok[tl++] = s->c; tok[tl] = 0;
         advance(s);
         while (isgraph((unsigned char)s->c) && s->c != '[' && tl < TOKEN_MAX) {
@@ -199,7 +215,8 @@ static int parse_statements(cursor *s, qsim_circuit *c, int have_register, long 
             seek_operand(s);
             if (!read_int(s, &n) || n < 0 || n > 40) { qsim_set_circuit_error("bad register size in qubit statement"); return QSIM_ERR_PARSE; }
             c->num_q = n;
-            have_register = 1;
+            have_register = *have_reg = 1;
+            c->count = 0; c->n2 = 0; c->n4 = 0; /* a fresh |0...0>: gates read so far are void (:168-177) */
             while (s->c != '\n' && !s->eof) advance(s);
             continue;
         }
@@ -232,7 +249,11 @@ static int parse_openqasm(cursor *s, qsim_circuit *c) {
         do advance(s); while (s->c != ';' && !s->eof);
         do advance(s); while (separator(s->c, 0) && !s->eof);
     }
-    return parse_statements(s, c, 0, -1);
+    int have_register = 0;
+    const int rc = parse_statements(s, c, &have_register, -1);
+    if (rc) return rc;
+    if (!have_register) { qsim_set_circuit_error("no qubit statement in the circuit file"); return QSIM_ERR_PARSE; }
+    return QSIM_OK;
 }
 
 /* `<num_qubit> <num_gates>` then the same gate statements (`h q[0];`, `cx q[0], q[1];`, `$k` operands),
@@ -248,7 +269,8 @@ static int parse_counted(cursor *s, qsim_circuit *c) {
     advance(s);
     while (separator(s->c, 0) && !s->eof) advance(s);
     if (s->eof || ng == 0) return QSIM_OK;
-    return parse_statements(s, c, 1, ng);
+    int have_register = 1;
+    return parse_statements(s, c, &have_register, ng);
 }
 
 int qsim_circuit_parse_text(const char *text, size_t len, qsim_circuit **out) {

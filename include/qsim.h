@@ -129,7 +129,8 @@ int qsim_sync(qsim_state *s);  /* flush, then wait for the stream */
 int qsim_read(qsim_state *s, uint64_t first, uint64_t count, double *out_re_im);
 int qsim_write(qsim_state *s, uint64_t first, uint64_t count, const double *in_re_im);
 int qsim_norm2(qsim_state *s, double *out); /* sum |a|^2 computed on the device */
-void *qsim_device_ptr(qsim_state *s);        /* amplitude array in HBM */
+void *qsim_device_ptr(qsim_state *s);        /* amplitude array in HBM: launches pending gates and writes a lazily held
+                                              * |0...0> first (work is queued on qsim_stream(), not waited for); NULL on error */
 void *qsim_stream(qsim_state *s);            /* the hipStream_t every launch goes to */
 
 /* ---- measurement post-path (dead code in the reference's main, quantum_simulator.c:67-73) ---- */

@@ -164,3 +164,35 @@ def test_cpp_planner_equals_python_restatement(world, n, depth, seed, vocab):
                         assert x[1] == y[1] and np.array_equal(x[2], y[2])
                     else:
                         assert x[1] == y[1]
+
+
+def test_launcher_spawns_ranks_as_children():
+    """bench.py --gpus N (no external launcher) starts its ranks through launch.spawn_ranks: here 2 gloo ranks of a
+    probe script go through the same function; the parent relays rank 0's line and the exit code."""
+    import json
+    import sys
+    from gpu_quantum_simulator_amd import launch
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rank_probe.py")
+    cmd = launch.rank_command(2, probe, ["--x", "1"], port=12345)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and cmd[-3:] == [probe, "--x", "1"]
+    rc, out = launch.spawn_ranks(2, probe, ["--x", "1"], timeout=300)
+    assert rc == 0, out
+    line = json.loads([ln for ln in out.splitlines() if ln.startswith('{"metric"')][-1])
+    assert line["world"] == 2 and line["sum"] == 3.0 and line["argv"] == ["--x", "1"]
+
+
+def test_bench_plain_command_with_more_gpus_than_present_fails_cleanly():
+    """`python bench.py --gpus 2` where fewer GPUs exist: non-zero exit, a clear message, no hang, no JSON line."""
+    import subprocess
+    import sys
+    from gpu_quantum_simulator_amd import launch
+    present = launch.count_gpus()
+    if torch.cuda.device_count() >= 2 or (present or 0) >= 2:
+        pytest.skip("two GPUs are present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0
+    assert "2 GPUs requested" in p.stderr and "present" in p.stderr
+    assert '{"metric"' not in p.stdout

@@ -88,7 +88,56 @@ def test_parse_errors():
     with pytest.raises(_lib.QsimError) as e:
         Circuit.from_file("/nonexistent/file.qasm")
     assert e.value.code == _lib.ERR_OPEN
-    assert len(Circuit.from_text(hdr + "qubit[2] q;\n")) == 0  # empty circuit is fine
+    assert len(Circuit.from_text(hdr + "qubit[2] q;")) == 0  # empty circuit (nothing after the qubit line) is fine
+    with pytest.raises(_lib.QsimError, match="no qubit statement"):
+        Circuit.from_text(hdr)
+
+
+def test_parser_corners_pinned_to_the_oracle(oracle, tmp_path):
+    """Two corners of quantum_simulator.c's statement loop (VERDICT r01 'missing' 7), checked against the oracle — and
+    against the compiled reference itself where oracle/_ref exists (this container):
+      * a second `qubit` statement re-initialises the state (:162-181): earlier gates are void;
+      * `qubit` as the LAST statement followed by a newline is an 'Unknown token' error (:147-151,:179-180);
+        with no character after it the file is accepted and yields |0...0>."""
+    hdr = 'OPENQASM 3.0;\ninclude "stdgates.inc";\n'
+    twice = tmp_path / "twice.qasm"
+    twice.write_text(hdr + "qubit[3] q;\nh q[0];\ncx q[0], q[2];\nqubit[2] q;\nx q[1];\nh q[0];\n")
+    n, want, _, gates = oracle.run_qasm(str(twice))
+    c = Circuit.from_file(str(twice))
+    assert (c.num_qubits, len(c)) == (n, 2) == (2, 2)
+    assert c.gate(0)[:2] == ("u1", 1) and c.gate(1)[:2] == ("u1", 0)
+    got = replay_schedule(n, c.schedule(fuse=0))
+    assert np.max(np.abs(got - want)) < TOL
+    # an operand that was legal under the FIRST register but not under the second is rejected
+    with pytest.raises(_lib.QsimError, match="out of range"):
+        Circuit.from_text(hdr + "qubit[3] q;\nh q[0];\nqubit[2] q;\nx q[2];\n")
+
+    last_nl = tmp_path / "qubit_last_nl.qasm"
+    last_nl.write_text(hdr + "qubit[3] q;\n")
+    with pytest.raises(RuntimeError, match="unknown token"):
+        oracle.run_qasm(str(last_nl))
+    with pytest.raises(_lib.QsimError, match="Unknown token: \n") as e:
+        Circuit.from_file(str(last_nl))
+    assert e.value.code == _lib.ERR_PARSE
+    with pytest.raises(_lib.QsimError, match="Unknown token:  "):
+        Circuit.from_text(hdr + "qubit[3] q;\n  ")  # the last blank read is the "token"
+
+    last = tmp_path / "qubit_last.qasm"
+    last.write_text(hdr + "qubit[3] q;")
+    n, want, _, gates = oracle.run_qasm(str(last))
+    c = Circuit.from_file(str(last))
+    assert (c.num_qubits, len(c)) == (n, gates) == (3, 0)
+    assert want[0] == 1 and not want[1:].any()
+
+    if oracle.have_reference():
+        for path, ok in ((twice, True), (last, True), (last_nl, False)):
+            if ok:
+                rn, ramps = oracle.reference_run_qasm(str(path))
+                on, oamps, _, _ = oracle.run_qasm(str(path))
+                assert rn == on and ramps.tobytes() == oamps.tobytes()
+            else:
+                with pytest.raises(RuntimeError, match="NULL"):
+                    oracle.reference_run_qasm(str(path))
 
 
 @pytest.mark.parametrize("fuse", [0, 1, 2, 3])

@@ -49,6 +49,7 @@ def parse_args(argv=None):
     ap.add_argument("--tile-low-bits", type=int, default=None)
     ap.add_argument("--tile-max-ops", type=int, default=None)
     ap.add_argument("--grid-cap", type=int, default=None)
+    ap.add_argument("--tile-threads", type=int, default=None)
     ap.add_argument("--probe", type=int, default=None, metavar="Q",
                     help="single-qubit roofline probe instead of the random circuit: `depth` h gates on qubit Q, fusion off")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
@@ -284,7 +285,8 @@ def main():
     n = args.qubits + (int(round(math.log2(b.world))) if args.scaling == "weak" else 0)
     seed = args.seed if args.seed is not None else 20240117 + n
     opts = {k: v for k, v in (("tile_bits", args.tile_bits), ("tile_low_bits", args.tile_low_bits),
-                              ("tile_max_ops", args.tile_max_ops), ("grid_cap", args.grid_cap)) if v is not None}
+                              ("tile_max_ops", args.tile_max_ops), ("grid_cap", args.grid_cap),
+                              ("tile_threads", args.tile_threads)) if v is not None}
     head = b.measure(n, args.depth, args.vocabulary, seed, args.steps, args.warmup, args.fuse, opts,
                      probe_q=args.probe, with_1q_probe=True)
 

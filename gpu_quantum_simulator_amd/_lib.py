@@ -15,6 +15,7 @@ GATE_U1, GATE_CX, GATE_U2, GATE_U3 = 1, 2, 3, 4
 OPT_FUSE, OPT_PROFILE, OPT_TILE_BITS, OPT_TILE_LOW_BITS, OPT_MAX_PENDING, OPT_TILE_MAX_OPS, OPT_GRID_CAP, OPT_TILE_THREADS = range(1, 9)
 OPT_TILE_PAD_FROM = 9
 OPT_DEBUG_SKIP_OPS = 10
+OPT_DEBUG_SKIP_MEM = 11
 K_NAMES = ("init", "gate1", "gate1_lo", "phase", "cx", "gate2", "tile", "pack")
 K_COUNT = len(K_NAMES)
 
@@ -134,7 +135,8 @@ def load() -> ctypes.CDLL:
                 import torch  # noqa: F401
             except ImportError:
                 pass
-        lib = ctypes.CDLL(LIB_PATH)
+        # QSIM_LIB: another build of the same library (A/B runs of kernel variants from tools/); never a different backend
+        lib = ctypes.CDLL(os.environ.get("QSIM_LIB") or LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = header and library disagree
             fn.restype = res

@@ -76,7 +76,7 @@ struct qsim_state {
     bool owns = false;
     size_t amp_bytes() const { return f32 ? 8 : 16; }
     // options
-    int fuse = 3, profile = 0, tile_bits = 12, tile_low_bits = 3, tile_max_ops = 32, grid_cap = 0, tile_threads = 0, tile_pad_from = 10, debug_skip_ops = 0;
+    int fuse = 3, profile = 0, tile_bits = 12, tile_low_bits = 3, tile_max_ops = 32, grid_cap = 0, tile_threads = 0, tile_pad_from = 10, debug_skip_ops = 0, debug_skip_mem = 0;
     long max_pending = 1L << 16;
     // queue
     std::vector<QueuedGate> queue;
@@ -200,6 +200,9 @@ extern "C" int qsim_set_option(qsim_state *s, int option, long value) {
     case QSIM_OPT_DEBUG_SKIP_OPS:
         s->debug_skip_ops = value != 0;
         break;
+    case QSIM_OPT_DEBUG_SKIP_MEM:
+        s->debug_skip_mem = value != 0;
+        break;
 
     case QSIM_OPT_TILE_THREADS:
         if (value != 0 && value != 256 && value != 512 && value != 1024)
@@ -224,6 +227,7 @@ extern "C" long qsim_get_option(const qsim_state *s, int option) {
     case QSIM_OPT_TILE_THREADS: return s->tile_threads;
     case QSIM_OPT_TILE_PAD_FROM: return s->tile_pad_from;
     case QSIM_OPT_DEBUG_SKIP_OPS: return s->debug_skip_ops;
+    case QSIM_OPT_DEBUG_SKIP_MEM: return s->debug_skip_mem;
     default: return -1;
     }
 }
@@ -523,7 +527,7 @@ static int launch_pass(qsim_state *s, const Pass &p) {
             bare.n_scale = 0;
             e = launch_tile(cfg, s->amps, s->f32, bare, d, 0, threads, from_zero_ket, s->zero_ket_amp);
         } else {
-            e = launch_tile(cfg, s->amps, s->f32, p.geom, d, (int)need, threads, from_zero_ket, s->zero_ket_amp);
+            e = launch_tile(cfg, s->amps, s->f32, p.geom, d, (int)need, threads, from_zero_ket, s->zero_ket_amp, s->debug_skip_mem != 0);
         }
         break;
     }

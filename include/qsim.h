@@ -59,8 +59,10 @@ enum {
     QSIM_OPT_GRID_CAP = 7,     /* 0: one workgroup per work tile; >0: at most that many workgroups (grid-stride loop) */
     QSIM_OPT_TILE_PAD_FROM = 9,/* first index bit used to fill unused high slots of a tile (default 10) */
     QSIM_OPT_TILE_THREADS = 8, /* threads per tile workgroup: 0 auto (256 below 2^12 amplitudes, else 512), 256, 512, 1024 */
-    QSIM_OPT_DEBUG_SKIP_OPS = 10 /* measurement aid, default 0: 1 = tile passes move their tiles HBM -> LDS -> HBM but apply
+    QSIM_OPT_DEBUG_SKIP_OPS = 10,/* measurement aid, default 0: 1 = tile passes move their tiles HBM -> LDS -> HBM but apply
                                   * no blocks (amplitudes are then WRONG); splits a pass's memory time from its compute time */
+    QSIM_OPT_DEBUG_SKIP_MEM = 11 /* measurement aid, default 0: 1 = tile passes apply their blocks to zero-filled tiles and
+                                  * neither load nor store the state (amplitudes are then WRONG): the block phase alone */
 };
 
 /* Kernel classes reported by qsim_get_stats. */

@@ -136,6 +136,29 @@ def cpu_baseline(n, gates, budget_s):
             "sample": f"first {done} gate statements of the same n={n} circuit, {dt:.1f} s, 1 thread, state resident in host RAM"}
 
 
+def exchange_model(depth, vocabulary, ms_per_step_n30, link_gbps=50.0, pack_gbps=5000.0):
+    """What the planner's cost model predicts for the multi-GPU configs of BASELINE.json, computed from the plans alone
+    (host work, no GPU): exchanges, qubits swapped, bytes per rank, exchange time, and the step time that follows when
+    the local passes scale with the shard size from the measured 1-GPU n=30 step."""
+    from gpu_quantum_simulator_amd import circuits, gate_matrix
+    from gpu_quantum_simulator_amd.distributed import ShardPlan, normalize_gates
+    rows = []
+    for n, P in ((30, 2), (30, 4), (30, 8), (33, 8)):
+        gates = normalize_gates(circuits.random_gates(n, depth, 20240117 + n, vocabulary), gate_matrix)
+        plan = ShardPlan(n, P.bit_length() - 1, gates, 0)
+        nbytes, secs = plan.predict(link_gbps, pack_gbps)
+        local_ms = ms_per_step_n30 * (2.0 ** (n - 30)) / P
+        rows.append({"qubits": n, "ranks": P, "exchanges": plan.exchanges,
+                     "qubits_swapped": [len(st[1]) for st in plan.steps if st[0] == "exchange"],
+                     "bytes_sent_per_rank": nbytes, "predicted_exchange_ms": 1e3 * secs,
+                     "predicted_local_ms": local_ms, "predicted_step_ms": local_ms + 1e3 * secs,
+                     "vs_ideal": (local_ms + 1e3 * secs) / (ms_per_step_n30 * (2.0 ** (n - 30)) / P)})
+    return {"assumptions": {"link_gbps_per_direction": link_gbps, "pack_gbps": pack_gbps,
+                            "note": "xGMI link ~76.8 GB/s per direction peak (7 x ~153 GB/s bidirectional per GPU), 65 % assumed; "
+                                    "no overlap of exchange and local passes; local passes scale with the shard size"},
+            "configs": rows}
+
+
 def launch_ranks(args):
     """--gpus N > 1 without a launcher: become the parent of N rank processes.  Nothing here touches the GPU."""
     from gpu_quantum_simulator_amd import launch
@@ -252,8 +275,10 @@ class Bench:
                                "qubits_swapped": [len(s[1]) for s in sim.plan.steps if s[0] == "exchange"],
                                "bytes_sent_per_rank_per_step": xb, "seconds_per_step": xs,
                                "xgmi_gbps_per_rank": (xb / xs / 1e9) if xs > 0 else None,
+                               "backend": getattr(sim, "exchange_backend", None),
                                "predicted": getattr(sim, "exchange_prediction", None),
-                               "note": "seconds: pack + send/recv as seen by rank 0's host clock"}
+                               "note": "seconds: pack + send/recv of rank 0 (rccl-native: HIP events on the engine's stream; "
+                                       "torch.distributed: host clock incl. the stream hand-offs)"}
         sim.close()
         del sim
         return res
@@ -293,7 +318,11 @@ def main():
     # other register sizes, same generator and defaults (north_star: n = 24/28/30/32)
     sizes = []
     if args.sizes and args.probe is None and args.precision == 64:
-        for m in [int(x) for x in args.sizes.split(",") if x.strip()]:
+        want = [int(x) for x in args.sizes.split(",") if x.strip()]
+        weak = args.qubits + int(round(math.log2(b.world)))  # the same shard size as the 1-GPU headline (n=33 on 8 GPUs)
+        if b.world > 1 and weak not in want:
+            want.append(weak)
+        for m in want:
             if m == n or m - int(round(math.log2(b.world))) < 14:
                 continue
             r = b.measure(m, args.depth, args.vocabulary, 20240117 + m, args.size_steps, 1, args.fuse, opts)
@@ -328,6 +357,8 @@ def main():
         cpu = not args.no_cpu_baseline and args.gpus == 1 and b.dist is None
         if cpu:
             out["cpu_baseline"] = cpu_baseline(n, head["gates"], args.cpu_seconds)
+        if cpu and args.probe is None and n == 30:
+            out["exchange_model"] = exchange_model(args.depth, args.vocabulary, ms_per_step)
         if sizes:
             table = []
             for r in sizes:

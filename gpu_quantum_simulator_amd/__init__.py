@@ -7,11 +7,11 @@ importing it never loads anything from oracle/.
 """
 from . import circuits  # noqa: F401  (pure Python, no native code)
 
-__all__ = ["circuits", "Simulator", "Circuit", "Cluster", "run_qasm", "gate_matrix", "ShardPlanHandle"]
+__all__ = ["circuits", "Simulator", "Circuit", "Cluster", "run_qasm", "gate_matrix", "ShardPlanHandle", "RankComm"]
 
 
 def __getattr__(name):  # lazy: `import gpu_quantum_simulator_amd.circuits` must work before the library is built
-    if name in ("Simulator", "Circuit", "Cluster", "run_qasm", "gate_matrix", "ShardPlanHandle"):
+    if name in ("Simulator", "Circuit", "Cluster", "run_qasm", "gate_matrix", "ShardPlanHandle", "RankComm"):
         from . import simulator
         return getattr(simulator, name)
     raise AttributeError(name)

@@ -65,6 +65,10 @@ SIGNATURES = {
     "qsim_draw_randn": (c_double, []),
     "qsim_putb": (None, [ctypes.c_longlong, c_int, c_char_p]),
     "qsim_pack_bits": (c_int, [c_void_p, POINTER(c_int), c_int, c_void_p]),
+    "qsim_pack_bits_to": (c_int, [c_void_p, POINTER(c_int), c_int, POINTER(c_void_p)]),
+    "qsim_swap_buffer": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "qsim_block_prob_masked": (c_int, [c_void_p, c_uint64, c_uint64, _DP]),
+    "qsim_gather_masked": (c_int, [c_void_p, c_uint64, c_uint64, _DP]),
     "qsim_scale": (c_int, [c_void_p, c_double, c_double]),
     "qsim_cluster_create": (c_int, [POINTER(c_void_p), c_int, c_int, POINTER(c_int)]),
     "qsim_cluster_destroy": (None, [c_void_p]),
@@ -79,6 +83,14 @@ SIGNATURES = {
     "qsim_cluster_sample": (c_int, [c_void_p, _DP, c_long, POINTER(c_uint64)]),
     "qsim_cluster_exchange_stats": (c_int, [c_void_p, POINTER(c_uint64), _DP]),
     "qsim_cluster_error": (c_char_p, []),
+    "qsim_cluster_exchange_mode": (c_char_p, [c_void_p]),
+    "qsim_shard_plan_predict": (c_int, [c_void_p, c_double, c_double, _DP, _DP]),
+    "qsim_rccl_unique_id": (c_int, [c_void_p]),
+    "qsim_rank_comm_create": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "qsim_rank_comm_destroy": (None, [c_void_p]),
+    "qsim_rank_comm_exchange": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), c_int]),
+    "qsim_rank_comm_stats": (c_int, [c_void_p, POINTER(c_uint64), _DP, _DP, c_int]),
+    "qsim_rank_comm_loopback": (c_int, [c_void_p, c_uint64]),
     "qsim_shard_plan_create": (c_int, [POINTER(c_void_p), c_void_p, c_int]),
     "qsim_shard_plan_free": (None, [c_void_p]),
     "qsim_shard_plan_num_steps": (c_int, [c_void_p]),

@@ -21,6 +21,8 @@
 #include <string>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "circuit.h"
 #include "qsim_internal.h"
 
@@ -66,7 +68,11 @@ void needs_local(const LGate &g, int out[2], int &cnt) {
     }
 }
 
-std::vector<int> choose_globals(const std::vector<LGate> &gates, const std::vector<int> &pos, int n, int p, int m) {
+// local_only: candidates are the qubits that are local now, so an exchange swaps ALL p global qubits (k = p).  On a
+// fully connected node a k-qubit swap sends 2^k - 1 blocks of 2^-k of the shard over as many links at once, so its
+// time FALLS with k; whether the extra qubits it evicts come back too soon is what plan_cost decides.
+std::vector<int> choose_globals(const std::vector<LGate> &gates, const std::vector<int> &pos, int n, int p, int m, bool local_only = false) {
+    if (m < p) local_only = false; // fewer local qubits than global ones: nothing to choose from
     std::vector<long> nxt(n, kInf);
     int found = 0;
     for (size_t i = 0; i < gates.size() && found < n; i++) {
@@ -75,8 +81,9 @@ std::vector<int> choose_globals(const std::vector<LGate> &gates, const std::vect
         for (int k = 0; k < c; k++)
             if (nxt[q[k]] == kInf) { nxt[q[k]] = (long)i; found++; }
     }
-    std::vector<int> order(n);
-    for (int q = 0; q < n; q++) order[q] = q;
+    std::vector<int> order;
+    for (int q = 0; q < n; q++)
+        if (!local_only || pos[q] < m) order.push_back(q);
     // far next use first; then already-global (nothing to move); then a high position — same key as the Python twin
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
         if (nxt[a] != nxt[b]) return nxt[a] > nxt[b];
@@ -88,7 +95,7 @@ std::vector<int> choose_globals(const std::vector<LGate> &gates, const std::vect
     return order;
 }
 
-bool build_plan(int n, int p, const std::vector<LGate> &gates, Plan &plan) {
+bool build_plan_policy(int n, int p, const std::vector<LGate> &gates, Plan &plan, bool full_swap) {
     const int P = 1 << p, m = n - p;
     plan.n = n; plan.p = p; plan.m = m;
     std::vector<int> pos(n);
@@ -148,7 +155,7 @@ bool build_plan(int n, int p, const std::vector<LGate> &gates, Plan &plan) {
             plan.steps.push_back(std::move(st));
         }
         if (!deferred.empty()) {
-            std::vector<int> ng = choose_globals(deferred, pos, n, p, m);
+            std::vector<int> ng = choose_globals(deferred, pos, n, p, m, full_swap);
             std::vector<int> outgoing, incoming;
             for (int q : ng) if (pos[q] < m) outgoing.push_back(q);
             for (int q = 0; q < n; q++)
@@ -177,6 +184,27 @@ bool build_plan(int n, int p, const std::vector<LGate> &gates, Plan &plan) {
         remaining.swap(deferred);
     }
     plan.final_pos = pos;
+    return true;
+}
+
+// Exchange cost of a plan in integer units (so that the C++ planner and its Python twin decide identically): one
+// exchange of k qubits = a pack pass over the shard (2 S bytes of HBM traffic) + 2^-k of the shard over each of 2^k - 1
+// links in parallel.  With S / link = kLinkUnits and 2 S / HBM = kPackUnits (defaults: 50 GB/s per link direction, 5 TB/s
+// pack kernel, i.e. 200 : 1 per byte; qsim_shard_plan_predict takes the real figures) the cost is additive.
+constexpr long kLinkUnits = 25600, kPackUnits = 256;
+long plan_cost(const Plan &plan) {
+    long c = 0;
+    for (const Step &st : plan.steps)
+        if (st.exchange) c += kPackUnits + (kLinkUnits >> st.J.size());
+    return c;
+}
+
+// Two placement policies are planned in full and the cheaper plan (by plan_cost) is kept; ties keep the first.
+bool build_plan(int n, int p, const std::vector<LGate> &gates, Plan &plan) {
+    Plan keep, full;
+    if (!build_plan_policy(n, p, gates, keep, false)) return false;
+    if (p > 1 && build_plan_policy(n, p, gates, full, true) && plan_cost(full) < plan_cost(keep)) plan = std::move(full);
+    else plan = std::move(keep);
     return true;
 }
 
@@ -215,6 +243,12 @@ struct qsim_cluster {
     std::vector<int> pos; // logical -> physical after the last run
     uint64_t exchanges = 0;
     double exchange_bytes = 0; // per shard, summed over exchanges
+    // How blocks travel: every shard on its own device -> RCCL (one ncclGroup of sends + recvs per exchange, on the shard
+    // streams); every shard on the SAME device (virtual shards) -> the pack kernel writes its blocks straight into the
+    // members' spare buffers and the buffers change roles; anything else -> pack + device-to-device copies.
+    std::vector<ncclComm_t> comms;
+    bool same_device = false;
+    std::vector<hipEvent_t> packed; // per shard: its pack of the current exchange has finished
 };
 
 static thread_local std::string g_derr;
@@ -231,8 +265,12 @@ extern "C" const char *qsim_cluster_error(void) { return g_derr.c_str(); }
 
 extern "C" void qsim_cluster_destroy(qsim_cluster *c) {
     if (!c) return;
+    for (size_t r = 0; r < c->shard.size(); r++) (void)qsim_sync(c->shard[r]);
+    for (ncclComm_t comm : c->comms) (void)ncclCommDestroy(comm);
     for (size_t r = 0; r < c->shard.size(); r++) {
-        if (c->scratch[r]) { (void)hipSetDevice(c->devices[r]); (void)hipFree(c->scratch[r]); }
+        (void)hipSetDevice(c->devices[r]);
+        if (r < c->packed.size() && c->packed[r]) (void)hipEventDestroy(c->packed[r]);
+        if (c->scratch[r]) (void)hipFree(c->scratch[r]);
         qsim_destroy(c->shard[r]);
     }
     delete c;
@@ -279,6 +317,32 @@ extern "C" int qsim_cluster_create(qsim_cluster **out, int num_q, int num_shards
                     (void)hipDeviceEnablePeerAccess(c->devices[b], 0); // "already enabled" is fine
             }
     (void)hipGetLastError();
+    if (p > 0) {
+        bool same = true, distinct = true;
+        for (int a = 0; a < num_shards; a++)
+            for (int b = a + 1; b < num_shards; b++) {
+                if (c->devices[a] == c->devices[b]) distinct = false;
+                else same = false;
+            }
+        c->same_device = same;
+        c->packed.assign((size_t)num_shards, nullptr);
+        for (int r = 0; r < num_shards; r++) {
+            (void)hipSetDevice(c->devices[r]);
+            if (hipEventCreateWithFlags(&c->packed[r], hipEventDisableTiming) != hipSuccess) {
+                qsim_cluster_destroy(c);
+                return cfail(QSIM_ERR_DEVICE, "event creation failed");
+            }
+        }
+        if (distinct) { // one RCCL communicator per device, all in this process
+            c->comms.assign((size_t)num_shards, nullptr);
+            const ncclResult_t nr = ncclCommInitAll(c->comms.data(), num_shards, c->devices.data());
+            if (nr != ncclSuccess) {
+                c->comms.clear();
+                qsim_cluster_destroy(c);
+                return cfail(QSIM_ERR_DEVICE, "ncclCommInitAll failed: %s", ncclGetErrorString(nr));
+            }
+        }
+    }
     *out = c;
     return QSIM_OK;
 }
@@ -325,7 +389,80 @@ static int apply_local(qsim_cluster *c, const Step &st) {
     return QSIM_OK;
 }
 
-static int exchange(qsim_cluster *c, const Step &st) {
+// Same device for every shard: shard r's pack writes block j of its new layout straight into the spare buffer of group
+// member j (at block position mine(r)), then every shard takes its spare buffer — now complete — as its state.  One
+// kernel per shard and no copy stage; ordering is by events between the shard streams, the host never waits.
+static int exchange_direct(qsim_cluster *c, const Step &st) {
+    const int k = (int)st.J.size();
+    const size_t blk_bytes = ((size_t)16 << c->m) >> k;
+    for (int r = 0; r < c->P; r++) {
+        int mine;
+        std::vector<int> members;
+        peers_of(r, st.J, mine, members);
+        void *dsts[8];
+        for (int j = 0; j < (1 << k); j++) dsts[j] = (char *)c->scratch[members[j]] + (size_t)mine * blk_bytes;
+        const int rc = qsim_pack_bits_to(c->shard[r], st.Lsel.data(), k, dsts);
+        if (rc) return cfail(rc, "%s", qsim_last_error());
+        if (hipEventRecord(c->packed[r], (hipStream_t)qsim_stream(c->shard[r])) != hipSuccess) return cfail(QSIM_ERR_DEVICE, "event record failed");
+    }
+    // every stream waits for every pack: the members' packs filled this shard's new buffer, and nobody may write into a
+    // buffer (next exchange) that a straggler still reads
+    for (int r = 0; r < c->P; r++)
+        for (int o = 0; o < c->P; o++)
+            if (o != r && hipStreamWaitEvent((hipStream_t)qsim_stream(c->shard[r]), c->packed[o], 0) != hipSuccess)
+                return cfail(QSIM_ERR_DEVICE, "stream wait failed");
+    for (int r = 0; r < c->P; r++) {
+        void *buf = c->scratch[r];
+        const int rc = qsim_swap_buffer(c->shard[r], &buf);
+        if (rc) return cfail(rc, "%s", qsim_last_error());
+        c->scratch[r] = (double2 *)buf;
+    }
+    return QSIM_OK;
+}
+
+// One device per shard: RCCL.  Every shard packs into its own scratch; then ONE group holds, for every shard, the
+// 2^k - 1 sends of its scratch blocks and the 2^k - 1 receives into its state buffer, each pair of shards on its own
+// xGMI link (k = 1: the pairwise half-shard exchange; k = log2 P: an all-to-all over all P - 1 links at once).
+// Everything is stream-ordered on the shard streams (pack -> send/recv -> the next pass); the host does not wait.
+static int exchange_rccl(qsim_cluster *c, const Step &st) {
+    const int k = (int)st.J.size();
+    const size_t blk_bytes = ((size_t)16 << c->m) >> k;
+    for (int r = 0; r < c->P; r++) {
+        const int rc = qsim_pack_bits(c->shard[r], st.Lsel.data(), k, c->scratch[r]);
+        if (rc) return cfail(rc, "%s", qsim_last_error());
+    }
+    ncclResult_t nr = ncclGroupStart();
+    for (int r = 0; r < c->P && nr == ncclSuccess; r++) {
+        int mine;
+        std::vector<int> members;
+        peers_of(r, st.J, mine, members);
+        char *state = (char *)qsim_device_ptr(c->shard[r]);
+        const char *scr = (const char *)c->scratch[r];
+        hipStream_t stream = (hipStream_t)qsim_stream(c->shard[r]);
+        (void)hipSetDevice(c->devices[r]);
+        for (int b = 0; b < (1 << k) && nr == ncclSuccess; b++) {
+            if (b == mine) continue;
+            nr = ncclSend(scr + (size_t)b * blk_bytes, blk_bytes / 8, ncclDouble, members[b], c->comms[r], stream);
+            if (nr == ncclSuccess) nr = ncclRecv(state + (size_t)b * blk_bytes, blk_bytes / 8, ncclDouble, members[b], c->comms[r], stream);
+        }
+    }
+    const ncclResult_t ne = ncclGroupEnd();
+    if (nr == ncclSuccess) nr = ne;
+    if (nr != ncclSuccess) return cfail(QSIM_ERR_DEVICE, "RCCL exchange failed: %s", ncclGetErrorString(nr));
+    for (int r = 0; r < c->P; r++) { // the block a shard keeps
+        int mine;
+        std::vector<int> members;
+        peers_of(r, st.J, mine, members);
+        (void)hipSetDevice(c->devices[r]);
+        if (hipMemcpyAsync((char *)qsim_device_ptr(c->shard[r]) + (size_t)mine * blk_bytes, (const char *)c->scratch[r] + (size_t)mine * blk_bytes,
+                           blk_bytes, hipMemcpyDeviceToDevice, (hipStream_t)qsim_stream(c->shard[r])) != hipSuccess)
+            return cfail(QSIM_ERR_DEVICE, "exchange copy failed");
+    }
+    return QSIM_OK;
+}
+
+// Mixed placements (some shards share a device, some do not): pack, then device-to-device copies of the blocks.
+static int exchange_copies(qsim_cluster *c, const Step &st) {
     const int k = (int)st.J.size();
     const size_t blk_bytes = ((size_t)16 << c->m) >> k;
     for (int r = 0; r < c->P; r++) {
@@ -359,9 +496,24 @@ static int exchange(qsim_cluster *c, const Step &st) {
         const int rc = qsim_sync(c->shard[r]);
         if (rc) return cfail(rc, "%s", qsim_last_error());
     }
-    c->exchanges++;
-    c->exchange_bytes += (double)blk_bytes * ((1 << k) - 1);
     return QSIM_OK;
+}
+
+static int exchange(qsim_cluster *c, const Step &st) {
+    const int k = (int)st.J.size();
+    int rc;
+    if (!c->comms.empty()) rc = exchange_rccl(c, st);
+    else if (c->same_device && k <= 3) rc = exchange_direct(c, st);
+    else rc = exchange_copies(c, st);
+    if (rc) return rc;
+    c->exchanges++;
+    c->exchange_bytes += (double)(((size_t)16 << c->m) >> k) * ((1 << k) - 1);
+    return QSIM_OK;
+}
+
+extern "C" const char *qsim_cluster_exchange_mode(const qsim_cluster *c) {
+    if (!c || c->p == 0) return "none";
+    return !c->comms.empty() ? "rccl" : c->same_device ? "direct" : "copies";
 }
 
 // Plans and runs the circuit from the CURRENT state with the map reset to what the planner assumes, i.e. call
@@ -429,46 +581,72 @@ extern "C" int qsim_cluster_read(qsim_cluster *c, uint64_t first, uint64_t count
 }
 
 // measurement() of quantum_simulator.c:270-283 on a sharded state, in LOGICAL index order (the order the reference's
-// cumulative distribution runs in, whatever the qubit map of the last run left behind).  Each shard is streamed to the
-// host once in 64 MiB pieces and contributes to the sums of the 2^12-amplitude logical blocks it holds a part of — the
-// "P partial sums" of SURVEY 8f row 1, added in shard order; a draw then fetches only its own block.
+// cumulative distribution runs in, whatever the qubit map of the last run left behind).  A logical block = the 2^12
+// amplitudes that agree on logical bits >= 12.  On shard r it occupies the local positions holding logical bits < 12
+// (lo_mask), at the base given by the local positions holding logical bits >= 12 (hi_mask); logical bits sitting on
+// rank-id positions are fixed by r.  So every shard sums |a|^2 per block ON ITS DEVICE (qsim_block_prob_masked), the
+// host adds the "P partial sums" of SURVEY 8f row 1 in shard order, and a draw fetches only its own block
+// (qsim_gather_masked from the shards that hold a part of it).  Nothing else crosses PCIe: 2^(n-12) doubles per shard
+// plus 64 KiB per distinct block drawn.
 extern "C" int qsim_cluster_sample(qsim_cluster *c, const double *randoms, long shots, uint64_t *out) {
     if (!c || (shots > 0 && (!randoms || !out))) return cfail(QSIM_ERR_ARG, "NULL argument");
     constexpr int kBlockBits = 12;
     const int bb = c->n < kBlockBits ? c->n : kBlockBits;
-    const uint64_t N = 1ULL << c->n, nblocks = N >> bb, bsize = 1ULL << bb, M = 1ULL << c->m;
+    const uint64_t N = 1ULL << c->n, nblocks = N >> bb, bsize = 1ULL << bb;
     std::vector<int> inv(c->n); // physical bit -> logical qubit
     for (int q = 0; q < c->n; q++) inv[c->pos[q]] = q;
-    // logical index of a physical index, by halves of the local bits (a bit permutation is linear over OR)
-    const int lo_bits = c->m < 11 ? c->m : 11;
-    std::vector<uint64_t> t_lo(1ULL << lo_bits);
-    for (uint64_t j = 0; j < t_lo.size(); j++) {
-        uint64_t l = 0;
-        for (int b = 0; b < lo_bits; b++) l |= ((j >> b) & 1ULL) << inv[b];
-        t_lo[j] = l;
-    }
-    auto logical_hi = [&](uint64_t ph_hi) { // ph_hi = physical index >> lo_bits
-        uint64_t l = 0;
-        for (int b = lo_bits; b < c->n; b++) l |= ((ph_hi >> (b - lo_bits)) & 1ULL) << inv[b];
-        return l;
-    };
-    std::vector<double> prefix(nblocks, 0.0);
-    const uint64_t piece = M < (1ULL << 22) ? M : (1ULL << 22);
-    std::vector<double> buf(2 * piece);
-    for (int r = 0; r < c->P; r++)
-        for (uint64_t at = 0; at < M; at += piece) {
-            const int rc = qsim_read(c->shard[r], at, piece, buf.data());
-            if (rc) return cfail(rc, "%s", qsim_last_error());
-            for (uint64_t j = 0; j < piece; j++) {
-                const uint64_t ph = ((uint64_t)r << c->m) | (at + j);
-                const uint64_t l = logical_hi(ph >> lo_bits) | t_lo[ph & (t_lo.size() - 1)];
-                prefix[l >> bb] += buf[2 * j] * buf[2 * j] + buf[2 * j + 1] * buf[2 * j + 1];
-            }
+    uint64_t hi_mask = 0, lo_mask = 0; // local positions by the kind of logical bit they hold
+    for (int b = 0; b < c->m; b++) (inv[b] >= bb ? hi_mask : lo_mask) |= 1ULL << b;
+    std::vector<int> hi_pos, lo_pos; // ascending local positions = the order deposit() fills them in
+    for (int b = 0; b < c->m; b++) (inv[b] >= bb ? hi_pos : lo_pos).push_back(b);
+    // block id / in-block index contributed by the rank-id bits of shard r
+    auto rank_part = [&](int r, uint64_t &blk_bits, uint64_t &in_bits) {
+        blk_bits = in_bits = 0;
+        for (int g = 0; g < c->p; g++) {
+            const int L = inv[c->m + g];
+            if ((r >> g) & 1) (L >= bb ? blk_bits : in_bits) |= 1ULL << (L >= bb ? L - bb : L);
         }
+    };
+    std::vector<double> prefix(nblocks, 0.0), part((size_t)1 << hi_pos.size());
+    for (int r = 0; r < c->P; r++) {
+        const int rc = qsim_block_prob_masked(c->shard[r], hi_mask, lo_mask, part.data());
+        if (rc) return cfail(rc, "%s", qsim_last_error());
+        uint64_t rb, ri;
+        rank_part(r, rb, ri);
+        for (uint64_t w = 0; w < part.size(); w++) {
+            uint64_t blk = rb;
+            for (size_t j = 0; j < hi_pos.size(); j++)
+                if ((w >> j) & 1ULL) blk |= 1ULL << (inv[hi_pos[j]] - bb);
+            prefix[blk] += part[w];
+        }
+    }
     double acc = 0.0;
     for (uint64_t b = 0; b < nblocks; b++) { acc += prefix[b]; prefix[b] = acc; } // cumulative at the END of block b
-    std::vector<double> blk(2 * bsize);
+    std::vector<double> blk(2 * bsize), piece((size_t)2 << lo_pos.size());
     uint64_t cached = ~0ULL;
+    auto fetch_block = [&](uint64_t b) -> int {
+        for (int r = 0; r < c->P; r++) {
+            uint64_t rb, ri;
+            rank_part(r, rb, ri);
+            uint64_t gmask = 0; // block-id bits decided by rank-id positions
+            for (int g = 0; g < c->p; g++)
+                if (inv[c->m + g] >= bb) gmask |= 1ULL << (inv[c->m + g] - bb);
+            if ((b & gmask) != rb) continue; // this shard holds no part of block b
+            uint64_t base = 0;
+            for (size_t j = 0; j < hi_pos.size(); j++)
+                if ((b >> (inv[hi_pos[j]] - bb)) & 1ULL) base |= 1ULL << hi_pos[j];
+            const int rc = qsim_gather_masked(c->shard[r], base, lo_mask, piece.data());
+            if (rc) return cfail(rc, "%s", qsim_last_error());
+            for (uint64_t i = 0; i < ((uint64_t)1 << lo_pos.size()); i++) {
+                uint64_t in = ri;
+                for (size_t j = 0; j < lo_pos.size(); j++)
+                    if ((i >> j) & 1ULL) in |= 1ULL << inv[lo_pos[j]];
+                blk[2 * in] = piece[2 * i];
+                blk[2 * in + 1] = piece[2 * i + 1];
+            }
+        }
+        return QSIM_OK;
+    };
     for (long k = 0; k < shots; k++) {
         const double rnd = randoms[k];
         uint64_t lo = 0, hi = nblocks;
@@ -481,11 +659,8 @@ extern "C" int qsim_cluster_sample(qsim_cluster *c, const double *randoms, long 
         bool found = false;
         for (uint64_t b = lo; b < nblocks && !found; b++) {
             if (b != cached) {
-                for (uint64_t i = 0; i < bsize; i++) {
-                    const uint64_t ph = physical_index(c, b * bsize + i);
-                    const int rc = qsim_read(c->shard[ph >> c->m], ph & (M - 1), 1, blk.data() + 2 * i);
-                    if (rc) return cfail(rc, "%s", qsim_last_error());
-                }
+                const int rc = fetch_block(b);
+                if (rc) return rc;
                 cached = b;
             }
             double cum = b ? prefix[b - 1] : 0.0;
@@ -593,5 +768,174 @@ extern "C" int qsim_shard_plan_apply_local(const qsim_shard_plan *p, int step, i
         } else rc = qsim_scale(s, o.m[0].real(), o.m[0].imag());
         if (rc) return cfail(rc, "%s", qsim_last_error());
     }
+    return QSIM_OK;
+}
+
+// Predicted exchange cost of the plan on one fully connected xGMI node: bytes each rank sends, and the time of the
+// exchanges alone (pack pass + the largest per-link transfer; a k-qubit swap puts 2^-k of the shard on each of 2^k - 1
+// links, both directions at once).  link_gbps is per link and direction, pack_gbps the pack kernel's HBM rate.
+extern "C" int qsim_shard_plan_predict(const qsim_shard_plan *p, double link_gbps, double pack_gbps, double *bytes_per_rank, double *seconds) {
+    if (!p || link_gbps <= 0 || pack_gbps <= 0) return QSIM_ERR_ARG;
+    const double S = 16.0 * (double)(1ULL << p->plan.m);
+    double bytes = 0, secs = 0;
+    for (const Step &st : p->plan.steps) {
+        if (!st.exchange) continue;
+        const int k = (int)st.J.size();
+        const double blk = S / (double)(1 << k);
+        bytes += blk * ((1 << k) - 1);
+        secs += 2.0 * S / (pack_gbps * 1e9) + blk / (link_gbps * 1e9);
+    }
+    if (bytes_per_rank) *bytes_per_rank = bytes;
+    if (seconds) *seconds = secs;
+    return QSIM_OK;
+}
+
+// ---- one process per GPU: this rank's end of the exchanges, on RCCL -------------------------------------------------
+// The launcher's own channel (torch.distributed, MPI, a file) only carries the 128-byte RCCL id from rank 0 to the
+// others; every byte of state travels through ncclSend / ncclRecv issued here, on the shard's own stream, behind the
+// pack kernel and in front of the next pass — no host synchronisation inside an exchange.
+struct qsim_rank_comm {
+    ncclComm_t comm = nullptr;
+    qsim_state *shard = nullptr;
+    int world = 0, rank = 0, device = 0;
+    void *scratch = nullptr;
+    bool owns_scratch = false;
+    uint64_t exchanges = 0;
+    double bytes_sent = 0, ms = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timing; // start/stop of exchanges not yet resolved
+};
+
+static_assert(sizeof(ncclUniqueId) == QSIM_RCCL_ID_BYTES, "QSIM_RCCL_ID_BYTES must equal sizeof(ncclUniqueId)");
+
+extern "C" int qsim_rccl_unique_id(void *id) {
+    if (!id) return cfail(QSIM_ERR_ARG, "NULL argument");
+    ncclUniqueId uid;
+    const ncclResult_t nr = ncclGetUniqueId(&uid);
+    if (nr != ncclSuccess) return cfail(QSIM_ERR_DEVICE, "ncclGetUniqueId failed: %s", ncclGetErrorString(nr));
+    memcpy(id, &uid, sizeof uid);
+    return QSIM_OK;
+}
+
+extern "C" void qsim_rank_comm_destroy(qsim_rank_comm *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->shard) (void)qsim_sync(c->shard);
+    for (auto &pr : c->timing) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->owns_scratch && c->scratch) (void)hipFree(c->scratch);
+    delete c;
+}
+
+extern "C" int qsim_rank_comm_create(qsim_rank_comm **out, qsim_state *shard, int device, int world, int rank, const void *id, void *scratch) {
+    if (!out || !shard || !id) return cfail(QSIM_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    if (world < 1 || (world & (world - 1)) || rank < 0 || rank >= world) return cfail(QSIM_ERR_ARG, "bad world size / rank (%d, %d)", world, rank);
+    if (qsim_precision_bits(shard) != 64) return cfail(QSIM_ERR_ARG, "sharded states are fp64");
+    qsim_rank_comm *c = new qsim_rank_comm();
+    c->shard = shard; c->world = world; c->rank = rank; c->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return cfail(QSIM_ERR_DEVICE, "hipSetDevice(%d) failed", device); }
+    if (scratch) c->scratch = scratch;
+    else {
+        if (hipMalloc(&c->scratch, (size_t)16 << qsim_num_qubits(shard)) != hipSuccess) { delete c; return cfail(QSIM_ERR_ALLOC, "Malloc error"); }
+        c->owns_scratch = true;
+    }
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    const ncclResult_t nr = ncclCommInitRank(&c->comm, world, uid, rank);
+    if (nr != ncclSuccess) {
+        c->comm = nullptr;
+        qsim_rank_comm_destroy(c);
+        return cfail(QSIM_ERR_DEVICE, "ncclCommInitRank failed: %s", ncclGetErrorString(nr));
+    }
+    *out = c;
+    return QSIM_OK;
+}
+
+// Swaps k rank-id bits (shard_bits, ascending) with k local bits (local_bits, ascending) of this rank's shard.
+extern "C" int qsim_rank_comm_exchange(qsim_rank_comm *c, const int *shard_bits, const int *local_bits, int k) {
+    if (!c || !shard_bits || !local_bits) return cfail(QSIM_ERR_ARG, "NULL argument");
+    const int m = qsim_num_qubits(c->shard);
+    if (k < 1 || k > m || (1 << k) > c->world) return cfail(QSIM_ERR_ARG, "exchange of %d qubits unsupported here", k);
+    const std::vector<int> J(shard_bits, shard_bits + k);
+    for (int j : J)
+        if (j < 0 || (1 << j) >= c->world) return cfail(QSIM_ERR_ARG, "rank bit %d outside the world", j);
+    int mine;
+    std::vector<int> members;
+    peers_of(c->rank, J, mine, members);
+    const size_t blk_bytes = ((size_t)16 << m) >> k;
+    if (hipSetDevice(c->device) != hipSuccess) return cfail(QSIM_ERR_DEVICE, "hipSetDevice failed");
+    hipStream_t stream = (hipStream_t)qsim_stream(c->shard);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return cfail(QSIM_ERR_DEVICE, "event creation failed");
+    int rc = qsim_flush(c->shard); // everything queued so far belongs in front of the exchange
+    if (rc) return cfail(rc, "%s", qsim_last_error());
+    (void)hipEventRecord(e0, stream);
+    rc = qsim_pack_bits(c->shard, local_bits, k, c->scratch);
+    if (rc) return cfail(rc, "%s", qsim_last_error());
+    char *state = (char *)qsim_device_ptr(c->shard);
+    const char *scr = (const char *)c->scratch;
+    ncclResult_t nr = ncclGroupStart();
+    for (int b = 0; b < (1 << k) && nr == ncclSuccess; b++) {
+        if (b == mine) continue;
+        nr = ncclSend(scr + (size_t)b * blk_bytes, blk_bytes / 8, ncclDouble, members[b], c->comm, stream);
+        if (nr == ncclSuccess) nr = ncclRecv(state + (size_t)b * blk_bytes, blk_bytes / 8, ncclDouble, members[b], c->comm, stream);
+    }
+    const ncclResult_t ne = ncclGroupEnd();
+    if (nr == ncclSuccess) nr = ne;
+    if (nr != ncclSuccess) return cfail(QSIM_ERR_DEVICE, "RCCL exchange failed: %s", ncclGetErrorString(nr));
+    if (hipMemcpyAsync(state + (size_t)mine * blk_bytes, scr + (size_t)mine * blk_bytes, blk_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+        return cfail(QSIM_ERR_DEVICE, "exchange copy failed");
+    (void)hipEventRecord(e1, stream);
+    c->timing.emplace_back(e0, e1);
+    c->exchanges++;
+    c->bytes_sent += (double)blk_bytes * ((1 << k) - 1);
+    return QSIM_OK;
+}
+
+// Exchanges so far, bytes this rank sent, and the seconds its stream spent in them (pack + send/recv, HIP events on the
+// shard's stream; waits for the stream).  reset != 0 clears the counters afterwards.
+extern "C" int qsim_rank_comm_stats(qsim_rank_comm *c, uint64_t *exchanges, double *bytes_sent, double *seconds, int reset) {
+    if (!c) return cfail(QSIM_ERR_ARG, "NULL argument");
+    if (!c->timing.empty()) {
+        const int rc = qsim_sync(c->shard);
+        if (rc) return cfail(rc, "%s", qsim_last_error());
+        for (auto &pr : c->timing) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) c->ms += ms;
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        c->timing.clear();
+    }
+    if (exchanges) *exchanges = c->exchanges;
+    if (bytes_sent) *bytes_sent = c->bytes_sent;
+    if (seconds) *seconds = c->ms * 1e-3;
+    if (reset) { c->exchanges = 0; c->bytes_sent = 0; c->ms = 0; }
+    return QSIM_OK;
+}
+
+// Diagnostic: the first `count` doubles of the shard travel through ncclSend -> ncclRecv to this same rank (one group, on
+// the shard's stream) into the scratch buffer and are compared on the host.  It is the only way to drive the RCCL call
+// path of qsim_rank_comm_exchange where a single GPU is present (a 1-rank communicator has nobody to exchange with).
+extern "C" int qsim_rank_comm_loopback(qsim_rank_comm *c, uint64_t count) {
+    if (!c) return cfail(QSIM_ERR_ARG, "NULL argument");
+    const uint64_t cap = (uint64_t)2 << qsim_num_qubits(c->shard);
+    if (count < 1 || count > cap) return cfail(QSIM_ERR_ARG, "loopback count outside the shard");
+    if (hipSetDevice(c->device) != hipSuccess) return cfail(QSIM_ERR_DEVICE, "hipSetDevice failed");
+    hipStream_t stream = (hipStream_t)qsim_stream(c->shard);
+    const void *state = qsim_device_ptr(c->shard);
+    if (!state) return cfail(QSIM_ERR_DEVICE, "%s", qsim_last_error());
+    ncclResult_t nr = ncclGroupStart();
+    if (nr == ncclSuccess) nr = ncclSend(state, count, ncclDouble, c->rank, c->comm, stream);
+    if (nr == ncclSuccess) nr = ncclRecv(c->scratch, count, ncclDouble, c->rank, c->comm, stream);
+    const ncclResult_t ne = ncclGroupEnd();
+    if (nr == ncclSuccess) nr = ne;
+    if (nr != ncclSuccess) return cfail(QSIM_ERR_DEVICE, "RCCL loopback failed: %s", ncclGetErrorString(nr));
+    if (hipStreamSynchronize(stream) != hipSuccess) return cfail(QSIM_ERR_DEVICE, "stream sync failed");
+    std::vector<double> a(count), b(count);
+    if (hipMemcpy(a.data(), state, count * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(b.data(), c->scratch, count * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return cfail(QSIM_ERR_DEVICE, "copy back failed");
+    if (memcmp(a.data(), b.data(), count * 8) != 0) return cfail(QSIM_ERR_DEVICE, "RCCL loopback: received data differs");
     return QSIM_OK;
 }

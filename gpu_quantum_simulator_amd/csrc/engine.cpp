@@ -703,12 +703,65 @@ extern "C" int qsim_sample(qsim_state *s, const double *randoms, long shots, uin
     return QSIM_OK;
 }
 
-extern "C" int qsim_pack_bits(qsim_state *s, const int *bits, int nbits, void *dst) {
-    if (!s || !bits || !dst) return fail(QSIM_ERR_ARG, "NULL argument");
-    if (nbits < 1 || nbits > 8 || nbits > s->n) return fail(QSIM_ERR_ARG, "pack: %d bits unsupported", nbits);
+// Block sums and block contents for index sets that are bit-deposits rather than ranges (what a permuted qubit map of a
+// sharded state needs for the measurement post-path; see k_block_prob_masked).
+extern "C" int qsim_block_prob_masked(qsim_state *s, uint64_t hi_mask, uint64_t lo_mask, double *out) {
+    if (!s || !out) return fail(QSIM_ERR_ARG, "NULL argument");
+    const uint64_t all = s->n >= 64 ? ~0ULL : ((1ULL << s->n) - 1ULL);
+    if ((hi_mask & lo_mask) || ((hi_mask | lo_mask) & ~all)) return fail(QSIM_ERR_ARG, "masks must be disjoint and inside the state");
+    int rc = qsim_flush(s);
+    if (rc == QSIM_OK) rc = materialize_zero_ket(s);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    const uint64_t nblocks = 1ULL << __builtin_popcountll(hi_mask);
+    double *d_part = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_part, nblocks * sizeof(double)));
+    LaunchCfg cfg{s->stream, s->grid_cap};
+    hipError_t e = launch_block_prob_masked(cfg, s->amps, s->f32, hi_mask, lo_mask, d_part);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_part, nblocks * sizeof(double), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    (void)hipFree(d_part);
+    if (e != hipSuccess) return fail(QSIM_ERR_DEVICE, "qsim_block_prob_masked: %s", hipGetErrorString(e));
+    return QSIM_OK;
+}
+
+extern "C" int qsim_gather_masked(qsim_state *s, uint64_t base, uint64_t lo_mask, double *out) {
+    if (!s || !out) return fail(QSIM_ERR_ARG, "NULL argument");
+    const uint64_t all = s->n >= 64 ? ~0ULL : ((1ULL << s->n) - 1ULL);
+    if ((base & lo_mask) || ((base | lo_mask) & ~all)) return fail(QSIM_ERR_ARG, "base and mask must be disjoint and inside the state");
+    const uint64_t count = 1ULL << __builtin_popcountll(lo_mask);
+    if (count > (1ULL << 24)) return fail(QSIM_ERR_ARG, "gather of %llu amplitudes is not a block", (unsigned long long)count);
+    int rc = qsim_flush(s);
+    if (rc == QSIM_OK) rc = materialize_zero_ket(s);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    void *d_buf = nullptr;
+    HIP_TRY(hipMalloc(&d_buf, count * s->amp_bytes()));
+    LaunchCfg cfg{s->stream, s->grid_cap};
+    hipError_t e = launch_gather_masked(cfg, s->amps, s->f32, base, lo_mask, d_buf);
+    if (e == hipSuccess) {
+        if (!s->f32) e = hipMemcpyAsync(out, d_buf, count * 16, hipMemcpyDeviceToHost, s->stream);
+        else e = hipMemcpyAsync(reinterpret_cast<char *>(out) + 8 * count, d_buf, count * 8, hipMemcpyDeviceToHost, s->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    (void)hipFree(d_buf);
+    if (e != hipSuccess) return fail(QSIM_ERR_DEVICE, "qsim_gather_masked: %s", hipGetErrorString(e));
+    if (s->f32) widen_in_place(out, 2 * count);
+    return QSIM_OK;
+}
+
+static int pack_common(qsim_state *s, const int *bits, int nbits, void *dst, void *const *blocks) {
+    if (!s || !bits || (!dst && !blocks)) return fail(QSIM_ERR_ARG, "NULL argument");
+    if (nbits < 1 || nbits > (blocks ? 3 : 8) || nbits > s->n) return fail(QSIM_ERR_ARG, "pack: %d bits unsupported", nbits);
     for (int j = 0; j < nbits; j++)
         if (bits[j] < 0 || bits[j] >= s->n || (j && bits[j] <= bits[j - 1]))
             return fail(QSIM_ERR_ARG, "pack: bit positions must be ascending and inside the shard");
+    const size_t blk = (s->amp_bytes() << s->n) >> nbits;
+    for (int b = 0; b < (blocks ? 1 << nbits : 0); b++) {
+        if (!blocks[b]) return fail(QSIM_ERR_ARG, "pack: destination block %d is NULL", b);
+        const char *p = (const char *)blocks[b], *a = (const char *)s->amps;
+        if (p < a + (s->amp_bytes() << s->n) && a < p + blk) return fail(QSIM_ERR_ARG, "pack: a destination block overlaps the state");
+    }
     if (dst == s->amps) return fail(QSIM_ERR_ARG, "pack: dst must not alias the state");
     int rc = qsim_flush(s);
     if (rc == QSIM_OK) rc = materialize_zero_ket(s);
@@ -718,10 +771,30 @@ extern "C" int qsim_pack_bits(qsim_state *s, const int *bits, int nbits, void *d
     hipError_t e;
     {
         LaunchScope scope(s, QSIM_K_PACK);
-        e = launch_pack(cfg, s->amps, dst, s->f32, s->n, bits, nbits);
+        e = launch_pack(cfg, s->amps, dst, blocks, s->f32, s->n, bits, nbits);
     }
     if (e != hipSuccess) return fail(QSIM_ERR_DEVICE, "pack launch failed: %s", hipGetErrorString(e));
     account(s, QSIM_K_PACK, 2.0 * (double)s->amp_bytes() * (double)(1ULL << s->n));
+    return QSIM_OK;
+}
+
+extern "C" int qsim_pack_bits(qsim_state *s, const int *bits, int nbits, void *dst) { return pack_common(s, bits, nbits, dst, nullptr); }
+extern "C" int qsim_pack_bits_to(qsim_state *s, const int *bits, int nbits, void *const *dst_blocks) {
+    return pack_common(s, bits, nbits, nullptr, dst_blocks);
+}
+
+// Hands the state a different amplitude buffer and returns the old one: the second half of an exchange whose pack kernels
+// wrote every shard's NEW contents into the group members' spare buffers.  Both buffers hold 2^n amplitudes on the
+// state's device; whoever holds a buffer when it is destroyed frees it, so ownership simply travels with the pointers.
+extern "C" int qsim_swap_buffer(qsim_state *s, void **buffer) {
+    if (!s || !buffer || !*buffer) return fail(QSIM_ERR_ARG, "NULL argument");
+    if (!s->owns) return fail(QSIM_ERR_ARG, "swap_buffer: the state does not own its buffer (qsim_create_external)");
+    int rc = qsim_flush(s);
+    if (rc == QSIM_OK) rc = materialize_zero_ket(s);
+    if (rc) return rc;
+    void *old = s->amps;
+    s->amps = *buffer;
+    *buffer = old;
     return QSIM_OK;
 }
 

@@ -66,8 +66,14 @@ hipError_t launch_norm2(const LaunchCfg &cfg, const void *v, bool f32, int n, do
 hipError_t launch_block_prob(const LaunchCfg &cfg, const void *v, bool f32, int n, int block_bits, double *d_out) {
     return QSIM_DISPATCH(launch_block_prob(cfg, v, n, block_bits, d_out));
 }
-hipError_t launch_pack(const LaunchCfg &cfg, const void *in, void *out, bool f32, int n, const int *bits, int p) {
-    return QSIM_DISPATCH(launch_pack(cfg, in, out, n, bits, p));
+hipError_t launch_pack(const LaunchCfg &cfg, const void *in, void *out, void *const *blocks, bool f32, int n, const int *bits, int p) {
+    return QSIM_DISPATCH(launch_pack(cfg, in, out, blocks, n, bits, p));
+}
+hipError_t launch_block_prob_masked(const LaunchCfg &cfg, const void *v, bool f32, uint64_t hi_mask, uint64_t lo_mask, double *d_out) {
+    return QSIM_DISPATCH(launch_block_prob_masked(cfg, v, hi_mask, lo_mask, d_out));
+}
+hipError_t launch_gather_masked(const LaunchCfg &cfg, const void *v, bool f32, uint64_t base, uint64_t lo_mask, void *d_out) {
+    return QSIM_DISPATCH(launch_gather_masked(cfg, v, base, lo_mask, d_out));
 }
 #undef QSIM_DISPATCH
 

@@ -86,9 +86,14 @@ hipError_t launch_tile(const LaunchCfg &cfg, void *v, bool f32, const TileGeom &
 hipError_t launch_norm2(const LaunchCfg &cfg, const void *v, bool f32, int n, double *d_out /* zeroed */);
 // d_out[b] = sum of |a|^2 over amplitudes [b << block_bits, (b+1) << block_bits), fixed summation order
 hipError_t launch_block_prob(const LaunchCfg &cfg, const void *v, bool f32, int n, int block_bits, double *d_out);
+// d_out[w] = sum of |a|^2 over the amplitudes at deposit(w, hi_mask) | deposit(i, lo_mask), all i; 2^popcount(hi_mask) sums
+hipError_t launch_block_prob_masked(const LaunchCfg &cfg, const void *v, bool f32, uint64_t hi_mask, uint64_t lo_mask, double *d_out);
+// d_out[i] = v[base | deposit(i, lo_mask)], i < 2^popcount(lo_mask)
+hipError_t launch_gather_masked(const LaunchCfg &cfg, const void *v, bool f32, uint64_t base, uint64_t lo_mask, void *d_out);
 // out[dst] = in[src]: dst = (block << (n-p)) | rest, where block = the p bits of src at positions
 // `bits` (ascending) and rest = the remaining n-p bits of src in order.
-hipError_t launch_pack(const LaunchCfg &cfg, const void *in, void *out, bool f32, int n, const int *bits, int p);
+// `blocks` != NULL (p <= 3): block b goes to blocks[b] (2^(n-p) amplitudes each) instead of out + b * 2^(n-p).
+hipError_t launch_pack(const LaunchCfg &cfg, const void *in, void *out, void *const *blocks, bool f32, int n, const int *bits, int p);
 
 } // namespace qsim
 #endif

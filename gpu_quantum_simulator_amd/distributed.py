@@ -86,6 +86,11 @@ class ShardPlan:
                 self.exchanged_fraction += 1.0 - 2.0 ** (-len(st[1]))
         self.final_pos = self.handle.final_pos()
 
+    def predict(self, link_gbps: float = 50.0, pack_gbps: float = 5000.0):
+        """(bytes each rank sends, seconds in exchanges) under the planner's cost model: per exchange one pack pass plus
+        2^-k of the shard over each of 2^k - 1 links at once."""
+        return self.handle.predict(link_gbps, pack_gbps)
+
     def apply_local(self, step: int, sim) -> None:
         """Queues this rank's ops of a local step on a Simulator, natively."""
         self.handle.apply_local(step, self.rank, sim)
@@ -129,14 +134,21 @@ class HipShard:
         self.scratch = torch.empty((1 << m, 2), dtype=torch.float64, device=self.dev)
         self.sim = Simulator(m, device, fuse=fuse, profile=profile, external_ptr=self.state.data_ptr(), **opts)
         self._plan = None
+        self.device_index = device
+        self.comm = None  # RankComm: the exchanges on RCCL, issued by libqsim on the engine's own stream
+
+    def attach_comm(self, world: int, rank: int, uid: bytes):
+        from .simulator import RankComm
+        self.comm = RankComm(self.sim, self.device_index, world, rank, uid, scratch_ptr=self.scratch.data_ptr())
 
     def bind_plan(self, plan: "ShardPlan"):
         """Local steps are queued straight from the C++ plan (qsim_shard_plan_apply_local): no Python per gate."""
         self._plan = plan
 
-    # The buffers belong to torch's HIP runtime, libqsim runs on the system one (see _lib.load): device
-    # addresses are shared process-wide, so kernels work on them directly, but host<->device copies and
-    # stream ordering stay with the runtime that owns the allocation.  Hand-offs are host-side syncs.
+    # torch and libqsim share ONE HIP runtime in this process (both need libamdhip64.so.7 and the loader maps it once:
+    # torch's bundled copy when torch is imported first, which _lib.load() makes sure of), so libqsim's kernels, copies
+    # and RCCL calls work on torch-allocated buffers like on its own; only the STREAMS differ (the engine's stream vs
+    # torch's current stream), which is why a hand-off between the two is a sync.
     def reset(self, holds_index0: bool):
         self.sim.reset(holds_index0)
 
@@ -170,6 +182,9 @@ class HipShard:
         self.sim.reset_stats()
 
     def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
         self.sim.close()
 
 
@@ -189,9 +204,60 @@ class ShardedSimulator:
         self.plan = ShardPlan(n, p, normalize_gates(gates, gate_matrix), self.rank)
         self.shard = (shard_factory or HipShard)(self.m, device, fuse=fuse, profile=profile, **opts)
         _bind(self.shard, self.plan)
-        self.exchange_seconds = 0.0
-        self.exchange_bytes = 0
-        self._warm_up_links()
+        self._xsec = 0.0
+        self._xbytes = 0
+        bytes_per_rank, seconds = self.plan.predict()
+        self.exchange_prediction = {"model": "per exchange: pack pass (2 x shard bytes at 5 TB/s) + 2^-k of the shard per link "
+                                             "(50 GB/s per link and direction, 2^k - 1 links at once)",
+                                    "bytes_sent_per_rank_per_step": bytes_per_rank, "seconds_per_step": seconds}
+        self.exchange_backend = "torch.distributed"
+        if self.world > 1 and hasattr(self.shard, "attach_comm") and dist.get_backend() == "nccl":
+            self._attach_native_comm()
+        if self.exchange_backend == "torch.distributed":
+            self._warm_up_links()
+
+    def _attach_native_comm(self):
+        """Every byte of state then travels through ncclSend / ncclRecv issued by libqsim itself (csrc/dist.cpp
+        qsim_rank_comm_exchange); torch.distributed only carries the 128-byte RCCL id.  All ranks must agree on the
+        outcome, so a failure anywhere (reduced with MIN) sends every rank to the torch.distributed path."""
+        import sys
+        import torch
+        from .simulator import RankComm
+        dist, dev = self.dist, self.shard.state.device
+        t = torch.zeros(128, dtype=torch.uint8, device=dev)
+        ok = 1
+        try:
+            if self.rank == 0:
+                t.copy_(torch.frombuffer(bytearray(RankComm.unique_id()), dtype=torch.uint8))
+        except Exception as e:  # noqa: BLE001 - reported, then agreed on collectively
+            sys.stderr.write(f"[rank {self.rank}] RCCL id: {e}\n")
+            ok = 0
+        dist.broadcast(t, 0)
+        if ok:
+            try:
+                self.shard.attach_comm(self.world, self.rank, bytes(t.cpu().numpy().tobytes()))
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write(f"[rank {self.rank}] native RCCL communicator failed, using torch.distributed: {e}\n")
+                ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            self.exchange_backend = "rccl-native"
+        elif self.shard.comm is not None:
+            self.shard.comm.close()
+            self.shard.comm = None
+
+    @property
+    def exchange_seconds(self) -> float:
+        if self.exchange_backend == "rccl-native":
+            return self.shard.comm.stats()[2]  # HIP-event time on the engine's stream
+        return self._xsec
+
+    @property
+    def exchange_bytes(self) -> float:
+        if self.exchange_backend == "rccl-native":
+            return self.shard.comm.stats()[1]
+        return self._xbytes
 
     def _warm_up_links(self):
         """One tiny send/recv with every peer this rank will ever exchange with, so communicator set-up (RCCL builds
@@ -225,10 +291,12 @@ class ShardedSimulator:
         for i, st in enumerate(self.plan.steps):
             if st[0] == "local":
                 self.shard.apply_local(i)
+            elif self.exchange_backend == "rccl-native":
+                self.shard.comm.exchange(st[1], st[2])  # pack + one ncclGroup on the engine's stream; nothing waits here
             else:
                 t0 = time.perf_counter()
                 self._exchange(st[1], st[2])
-                self.exchange_seconds += time.perf_counter() - t0
+                self._xsec += time.perf_counter() - t0
 
     def _exchange(self, J, Lsel):
         dist, shard = self.dist, self.shard
@@ -241,7 +309,7 @@ class ShardedSimulator:
             # every rank takes part and member b IS rank b: one all-to-all collective (block b of the scratch goes to
             # rank b, block b of the state comes from rank b) — RCCL drives all P-1 xGMI links at once
             dist.all_to_all_single(st.view(-1), sc.view(-1))
-            self.exchange_bytes += (len(members) - 1) * sc[0].numel() * 8
+            self._xbytes += (len(members) - 1) * sc[0].numel() * 8
         else:
             ops = []
             for b, peer in enumerate(members):
@@ -250,7 +318,7 @@ class ShardedSimulator:
                 else:
                     ops.append(dist.P2POp(dist.isend, sc[b], peer))
                     ops.append(dist.P2POp(dist.irecv, st[b], peer))
-                    self.exchange_bytes += sc[b].numel() * 8
+                    self._xbytes += sc[b].numel() * 8
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         if st.is_cuda:
@@ -265,8 +333,10 @@ class ShardedSimulator:
 
     def reset_stats(self):
         self.shard.reset_stats()
-        self.exchange_seconds = 0.0
-        self.exchange_bytes = 0
+        self._xsec = 0.0
+        self._xbytes = 0
+        if self.exchange_backend == "rccl-native":
+            self.shard.comm.stats(reset=True)
 
     def norm2(self) -> float:
         import torch

@@ -207,6 +207,28 @@ class Simulator:
     def flush(self) -> None:
         check(_lib.load().qsim_flush(self._h))
 
+    def pack_bits_to(self, bits: Sequence[int], dst_ptrs: Sequence[int]) -> None:
+        """qsim_pack_bits_to: block b of the packed layout goes to dst_ptrs[b]."""
+        arr = (c_int * len(bits))(*bits)
+        ptrs = (c_void_p * len(dst_ptrs))(*dst_ptrs)
+        check(_lib.load().qsim_pack_bits_to(self._h, arr, len(bits), ptrs))
+
+    def swap_buffer(self, ptr: int) -> int:
+        """qsim_swap_buffer: the state takes `ptr` as its amplitude buffer; returns the buffer it held before."""
+        p = c_void_p(ptr)
+        check(_lib.load().qsim_swap_buffer(self._h, byref(p)))
+        return int(p.value)
+
+    def block_prob_masked(self, hi_mask: int, lo_mask: int) -> np.ndarray:
+        out = np.zeros(1 << bin(hi_mask).count("1"), dtype=np.float64)
+        check(_lib.load().qsim_block_prob_masked(self._h, hi_mask, lo_mask, _dp(out)))
+        return out
+
+    def gather_masked(self, base: int, lo_mask: int) -> np.ndarray:
+        out = np.zeros(2 << bin(lo_mask).count("1"), dtype=np.float64)
+        check(_lib.load().qsim_gather_masked(self._h, base, lo_mask, _dp(out)))
+        return out.view(np.complex128)
+
     def pack_bits(self, bits: Sequence[int], dst_ptr: int) -> None:
         """Shard re-layout ahead of a global<->local qubit exchange (qsim_pack_bits)."""
         arr = (c_int * len(bits))(*bits)
@@ -325,6 +347,11 @@ class Cluster:
         _lib.load().qsim_cluster_exchange_stats(self._h, byref(n), byref(b))
         return int(n.value), float(b.value)
 
+    @property
+    def exchange_mode(self) -> str:
+        """"rccl" | "direct" | "copies" | "none" (qsim_cluster_exchange_mode)."""
+        return (_lib.load().qsim_cluster_exchange_mode(self._h) or b"").decode()
+
     def close(self) -> None:
         if self._h:
             _lib.load().qsim_cluster_destroy(self._h)
@@ -390,9 +417,69 @@ class ShardPlanHandle:
         check(_lib.load().qsim_shard_plan_final_pos(self._h, pos))
         return list(pos)
 
+    def predict(self, link_gbps: float = 50.0, pack_gbps: float = 5000.0):
+        """(bytes each rank sends, seconds spent in exchanges) under the planner's cost model (qsim_shard_plan_predict)."""
+        b, t = c_double(), c_double()
+        check(_lib.load().qsim_shard_plan_predict(self._h, link_gbps, pack_gbps, byref(b), byref(t)))
+        return b.value, t.value
+
     def close(self) -> None:
         if self._h:
             _lib.load().qsim_shard_plan_free(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RankComm:
+    """qsim_rank_comm: this rank's end of the exchanges in a one-process-per-GPU job — RCCL send/recv issued by libqsim
+    on the shard's own stream.  `unique_id()` (rank 0) produces the bytes every rank passes to the constructor."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        rc = _lib.load().qsim_rccl_unique_id(buf)
+        if rc:
+            raise _lib.QsimError(rc, (_lib.load().qsim_cluster_error() or b"").decode())
+        return buf.raw
+
+    def __init__(self, sim: "Simulator", device: int, world: int, rank: int, uid: bytes, scratch_ptr: Optional[int] = None):
+        self._h = c_void_p()
+        lib = _lib.load()
+        buf = ctypes.create_string_buffer(bytes(uid), 128)
+        rc = lib.qsim_rank_comm_create(byref(self._h), sim._h, device, world, rank, buf,
+                                       c_void_p(scratch_ptr) if scratch_ptr else None)
+        if rc:
+            raise _lib.QsimError(rc, (lib.qsim_cluster_error() or b"").decode())
+
+    def exchange(self, shard_bits: Sequence[int], local_bits: Sequence[int]) -> None:
+        k = len(shard_bits)
+        rc = _lib.load().qsim_rank_comm_exchange(self._h, (c_int * k)(*shard_bits), (c_int * k)(*local_bits), k)
+        if rc:
+            raise _lib.QsimError(rc, (_lib.load().qsim_cluster_error() or b"").decode())
+
+    def loopback(self, count: int) -> None:
+        """`count` doubles of the shard through ncclSend -> ncclRecv to this same rank (qsim_rank_comm_loopback)."""
+        rc = _lib.load().qsim_rank_comm_loopback(self._h, count)
+        if rc:
+            raise _lib.QsimError(rc, (_lib.load().qsim_cluster_error() or b"").decode())
+
+    def stats(self, reset: bool = False):
+        """(exchanges, bytes sent by this rank, seconds its stream spent in exchanges)."""
+        from ctypes import c_uint64
+        n, b, t = c_uint64(), c_double(), c_double()
+        rc = _lib.load().qsim_rank_comm_stats(self._h, byref(n), byref(b), byref(t), 1 if reset else 0)
+        if rc:
+            raise _lib.QsimError(rc, (_lib.load().qsim_cluster_error() or b"").decode())
+        return int(n.value), float(b.value), float(t.value)
+
+    def close(self) -> None:
+        if self._h:
+            _lib.load().qsim_rank_comm_destroy(self._h)
             self._h = c_void_p()
 
     def __del__(self):

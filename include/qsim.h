@@ -157,6 +157,20 @@ void qsim_putb(long long n, int len, char *buf);
  * so block b is the contiguous piece rank-group member b must receive (RCCL send/recv or all-to-all of
  * 16<<(n-k) byte blocks over xGMI).  dst is caller-owned device memory of 16<<n bytes. */
 int qsim_pack_bits(qsim_state *s, const int *bits, int nbits, void *dst_device);
+/* The same re-layout with one destination per block (nbits <= 3): block b is written to dst_blocks[b] (2^(n-k)
+ * amplitudes each), e.g. straight into the spare buffer of the group member that will own it — another shard's buffer
+ * on the same device or a peer-mapped one — so that pack and transfer are one kernel.  qsim_swap_buffer then makes the
+ * spare buffer (now holding the shard's new contents) the state and hands back the old one. */
+int qsim_pack_bits_to(qsim_state *s, const int *bits, int nbits, void *const *dst_blocks);
+int qsim_swap_buffer(qsim_state *s, void **buffer_device);
+/* Block sums / block contents for blocks that are bit-deposits instead of ranges: block w = the amplitudes at
+ * deposit(w, hi_mask) | deposit(i, lo_mask), i = 0 .. 2^popcount(lo_mask) - 1 (deposit spreads the low bits of its first
+ * argument over the set bits of the mask, lowest first; the masks are disjoint).  After exchanges a LOGICAL block of the
+ * measurement post-path (quantum_simulator.c:256-283) is such a set of a shard's local positions: the sums are formed
+ * on the device and only 2^popcount(hi_mask) doubles, or one block, reach the host.
+ *   qsim_block_prob_masked: out[w] = sum_i |a|^2             qsim_gather_masked: out[i] = a[base | deposit(i, lo_mask)] */
+int qsim_block_prob_masked(qsim_state *s, uint64_t hi_mask, uint64_t lo_mask, double *out_host);
+int qsim_gather_masked(qsim_state *s, uint64_t base, uint64_t lo_mask, double *out_host_re_im);
 /* Multiplies every amplitude of the shard by (re, im): a diagonal gate on a global qubit is a per-rank scalar. */
 int qsim_scale(qsim_state *s, double re, double im);
 
@@ -179,10 +193,15 @@ int qsim_cluster_sync(qsim_cluster *c);
 int qsim_cluster_read(qsim_cluster *c, uint64_t logical_first, uint64_t count, double *out_re_im);
 int qsim_cluster_norm2(qsim_cluster *c, double *out);
 /* qsim_sample for a sharded state: basis indices in LOGICAL order for random numbers in [0,1] (measurement(),
- * quantum_simulator.c:270-283).  Streams every shard through the host once (bounded memory), so it costs a D2H of the
- * whole state: a post-path, not a hot path. */
+ * quantum_simulator.c:270-283), whatever qubit map the exchanges left behind.  Every shard forms the |a|^2 sums of the
+ * logical 2^12-amplitude blocks it holds a part of on its own device (qsim_block_prob_masked); the host adds the P
+ * partial sums per block in shard order and fetches only the blocks the draws land in (qsim_gather_masked). */
 int qsim_cluster_sample(qsim_cluster *c, const double *randoms, long shots, uint64_t *out_indices);
 int qsim_cluster_exchange_stats(const qsim_cluster *c, uint64_t *exchanges, double *bytes_per_shard);
+/* How this cluster moves blocks: "rccl" (every shard on its own device: one ncclGroup of ncclSend/ncclRecv per exchange,
+ * stream-ordered), "direct" (all shards on one device: the pack kernel writes into the members' buffers, which then
+ * change roles), "copies" (mixed placements: pack + device-to-device copies) or "none" (one shard). */
+const char *qsim_cluster_exchange_mode(const qsim_cluster *c);
 const char *qsim_cluster_error(void);
 /* The plan as an object (host only).  This is what the one-process-per-GPU driver executes: every rank builds the same
  * plan, applies its own local steps with qsim_shard_plan_apply_local on its shard state and performs the exchanges
@@ -198,6 +217,28 @@ int qsim_shard_plan_step(const qsim_shard_plan *p, int step, int *kind, int *k, 
 int qsim_shard_plan_final_pos(const qsim_shard_plan *p, int *pos /* num_q entries: logical -> physical */);
 int qsim_shard_plan_local_ops(const qsim_shard_plan *p, int step, int shard, qsim_local_op_cb cb, void *user);
 int qsim_shard_plan_apply_local(const qsim_shard_plan *p, int step, int shard, qsim_state *s);
+/* Cost model of the plan's exchanges on one fully connected xGMI node: bytes each rank sends, and seconds =
+ * sum over exchanges of (pack pass: 2 * shard bytes / pack_gbps) + (largest per-link transfer: 2^-k of the shard /
+ * link_gbps; a k-qubit swap uses 2^k - 1 links in both directions at once).  The planner itself keeps the cheaper of
+ * two placements (keep far-next-use globals vs swap all log2 P of them) under the same model with default rates. */
+int qsim_shard_plan_predict(const qsim_shard_plan *p, double link_gbps, double pack_gbps, double *bytes_per_rank, double *seconds);
+
+/* ---- one process per GPU: the exchanges on RCCL (pairwise ncclSend/ncclRecv of half-shards for one global
+ * qubit, one group of 2^k - 1 sends + receives for k of them) ----------------------------------------------------------
+ * Rank 0 calls qsim_rccl_unique_id and hands the QSIM_RCCL_ID_BYTES bytes to every rank over the launcher's own channel;
+ * each rank then joins with qsim_rank_comm_create (scratch: a caller-owned device buffer as large as the shard, or NULL
+ * to let the library allocate one).  qsim_rank_comm_exchange = pack kernel + ONE ncclGroup on the shard's stream, no
+ * host synchronisation; qsim_rank_comm_stats reports the HIP-event time its stream spent in exchanges. */
+#define QSIM_RCCL_ID_BYTES 128
+typedef struct qsim_rank_comm qsim_rank_comm;
+int qsim_rccl_unique_id(void *id_bytes);
+int qsim_rank_comm_create(qsim_rank_comm **out, qsim_state *shard, int device, int world, int rank, const void *id_bytes, void *scratch_device);
+void qsim_rank_comm_destroy(qsim_rank_comm *c);
+int qsim_rank_comm_exchange(qsim_rank_comm *c, const int *shard_bits, const int *local_bits, int k);
+int qsim_rank_comm_stats(qsim_rank_comm *c, uint64_t *exchanges, double *bytes_sent, double *seconds, int reset);
+/* Diagnostic: `count` doubles of the shard through ncclSend -> ncclRecv to this same rank, compared on the host (drives
+ * the RCCL call path where only one GPU is present). */
+int qsim_rank_comm_loopback(qsim_rank_comm *c, uint64_t count);
 
 int qsim_get_stats(qsim_state *s, qsim_stats *out); /* waits for outstanding profile events */
 int qsim_reset_stats(qsim_state *s);

@@ -18,13 +18,28 @@ class PyShardPlan:
     ops: ('u1', local_pos, U) | ('cx', cpos, tpos) | ('scale', z).  Every rank sees the same sequence of
     step kinds and the same exchanges."""
 
+    LINK_UNITS, PACK_UNITS = 25600, 256  # csrc/dist.cpp plan_cost: shard/link and pack pass in common integer units
+
     def __init__(self, n: int, p: int, gates: List[Tuple], rank: int, lookahead_free_start: bool = True):
         assert 0 <= p <= n - 2 or p == 0, "need at least two local qubits"
         self.n, self.p, self.m, self.rank = n, p, n - p, rank
-        self.steps: List[Tuple] = []
-        self.exchanges = 0
-        self.exchanged_fraction = 0.0  # sum over exchanges of the shard fraction sent
-        pos = list(range(n))  # logical -> physical
+        # two placement policies are planned in full; the cheaper plan under the exchange cost model is kept
+        keep = self._build(gates, lookahead_free_start, full_swap=False)
+        best = keep
+        if p > 1:
+            full = self._build(gates, lookahead_free_start, full_swap=True)
+            if self._cost(full[0]) < self._cost(keep[0]):
+                best = full
+        self.steps, self.exchanges, self.exchanged_fraction, self.final_pos = best
+
+    def _cost(self, steps) -> int:
+        return sum(self.PACK_UNITS + (self.LINK_UNITS >> len(s[1])) for s in steps if s[0] == "exchange")
+
+    def _build(self, gates, lookahead_free_start, full_swap):
+        steps: List[Tuple] = []
+        exchanges = 0
+        fraction = 0.0  # sum over exchanges of the shard fraction sent
+        pos = list(range(self.n))  # logical -> physical
         remaining = list(gates)
         first = True
         while remaining:
@@ -35,17 +50,17 @@ class PyShardPlan:
             first = False
             run, deferred = self._split(remaining, pos)
             if run:
-                self.steps.append(("local", self._emit(run, pos)))
+                steps.append(("local", self._emit(run, pos)))
             if deferred:
-                new_glob = self._choose_globals(deferred, pos)
+                new_glob = self._choose_globals(deferred, pos, local_only=full_swap)
                 J, Lsel = self._exchange(pos, new_glob)
                 if not J:
                     raise RuntimeError("planner made no progress")
-                self.steps.append(("exchange", tuple(J), tuple(Lsel)))
-                self.exchanges += 1
-                self.exchanged_fraction += 1.0 - 2.0 ** (-len(J))
+                steps.append(("exchange", tuple(J), tuple(Lsel)))
+                exchanges += 1
+                fraction += 1.0 - 2.0 ** (-len(J))
             remaining = deferred
-        self.final_pos = pos
+        return steps, exchanges, fraction, pos
 
     # -- which gates can run under the current placement
     def _needs_local(self, g) -> Tuple[int, ...]:
@@ -93,8 +108,11 @@ class PyShardPlan:
         return ops
 
     # -- placement
-    def _choose_globals(self, gates, pos) -> List[int]:
-        """The p logical qubits whose next use that needs locality is furthest away."""
+    def _choose_globals(self, gates, pos, local_only: bool = False) -> List[int]:
+        """The p logical qubits whose next use that needs locality is furthest away (local_only: among the qubits that
+        are local now, so that the exchange swaps all p global qubits)."""
+        if self.m < self.p:
+            local_only = False
         nxt = [INF] * self.n
         found = 0
         for i, g in enumerate(gates):
@@ -105,7 +123,8 @@ class PyShardPlan:
             if found == self.n:
                 break
         # prefer: far next use; then already-global (nothing to move); then a high position (long pack runs)
-        order = sorted(range(self.n), key=lambda q: (nxt[q], pos[q] >= self.m, pos[q]), reverse=True)
+        cand = [q for q in range(self.n) if not local_only or pos[q] < self.m]
+        order = sorted(cand, key=lambda q: (nxt[q], pos[q] >= self.m, pos[q]), reverse=True)
         return order[: self.p]
 
     def _relabel_free(self, pos, new_glob):

@@ -400,6 +400,104 @@ def test_pack_bits_layout(bits):
     assert np.array_equal(got, s[src])
 
 
+@pytest.mark.parametrize("bits", [(0,), (3, 11), (0, 5, 9), (11, 12, 13)])
+def test_pack_bits_to_separate_blocks_and_buffer_swap(bits):
+    """qsim_pack_bits_to writes block b of the same layout to its own destination (here: scattered over a larger torch
+    buffer, in reverse order) and qsim_swap_buffer makes a packed buffer the state — the two halves of the one-kernel
+    exchange qsim_cluster uses between shards that share a device."""
+    import torch
+    n = 14
+    k = len(bits)
+    blk = 1 << (n - k)
+    s = _rand_state(n, 51)
+    with Simulator(n) as sim:
+        sim.write(s)
+        ref = torch.zeros((1 << n, 2), dtype=torch.float64, device="cuda")
+        sim.pack_bits(bits, ref.data_ptr())
+        big = torch.zeros((2 << n, 2), dtype=torch.float64, device="cuda")
+        starts = [(2 * ((1 << k) - 1 - b)) * blk for b in range(1 << k)]  # reverse order, a gap after every block
+        sim.pack_bits_to(bits, [big.data_ptr() + 16 * st for st in starts])
+        sim.sync()
+        want = ref.cpu().numpy().reshape(-1).view(np.complex128)
+        got = big.cpu().numpy().reshape(-1).view(np.complex128)
+        for b, st in enumerate(starts):
+            assert np.array_equal(got[st:st + blk], want[b * blk:(b + 1) * blk]), b
+            assert not got[st + blk:st + 2 * blk].any()  # the gaps stay untouched
+        with pytest.raises(_lib.QsimError, match="overlaps the state"):
+            sim.pack_bits_to(bits, [sim.device_ptr] * (1 << k))
+    # swap: a state created by libqsim (it owns its buffer) trades it for a spare one of the same size
+    with Simulator(n) as sim:
+        sim.write(s)
+        spare_t = torch.zeros((1 << n, 2), dtype=torch.float64, device="cuda")
+        spare = spare_t.data_ptr()
+        old_ptr = sim.device_ptr
+        sim.pack_bits_to(bits[:1], [spare, spare + 16 * (1 << (n - 1))])  # spare = the state packed on bits[0]
+        was = sim.swap_buffer(spare)
+        assert was == old_ptr and sim.device_ptr == spare
+        got = sim.read()
+        d = np.arange(1 << n, dtype=np.int64)
+        rest, top = d & ((1 << (n - 1)) - 1), d >> (n - 1)
+        src = ((rest >> bits[0]) << (bits[0] + 1)) | (rest & ((1 << bits[0]) - 1)) | (top << bits[0])
+        assert np.array_equal(got, s[src])
+        assert sim.swap_buffer(was) == spare  # hand the original back before the state is destroyed (torch owns `spare`)
+        assert np.array_equal(sim.read(), s)
+
+
+def test_masked_block_sums_and_gather():
+    """qsim_block_prob_masked / qsim_gather_masked: blocks that are bit-deposits instead of ranges, against numpy."""
+    n = 13
+    s = _rand_state(n, 52)
+    rng = np.random.default_rng(3)
+
+    def deposit(x, mask):
+        out, j = 0, 0
+        for b in range(64):
+            if mask >> b & 1:
+                out |= ((x >> j) & 1) << b
+                j += 1
+        return out
+
+    with Simulator(n) as sim:
+        sim.write(s)
+        for _ in range(6):
+            bits = rng.permutation(n)
+            nlo = int(rng.integers(1, 9))
+            lo_mask = sum(1 << int(b) for b in bits[:nlo])
+            hi_mask = sum(1 << int(b) for b in bits[nlo:])
+            sums = sim.block_prob_masked(hi_mask, lo_mask)
+            idx = np.array([[deposit(w, hi_mask) | deposit(i, lo_mask) for i in range(1 << nlo)] for w in range(1 << (n - nlo))])
+            want = (np.abs(s[idx]) ** 2).sum(axis=1)
+            assert np.max(np.abs(sums - want)) < 1e-15
+            assert abs(sums.sum() - 1.0) < 1e-13
+            w = int(rng.integers(0, 1 << (n - nlo)))
+            assert np.array_equal(sim.gather_masked(deposit(w, hi_mask), lo_mask), s[idx[w]])
+        with pytest.raises(_lib.QsimError, match="disjoint"):
+            sim.block_prob_masked(0b11, 0b110)
+
+
+def test_rccl_rank_comm_on_one_gpu():
+    """The native RCCL call sites (csrc/dist.cpp) with the one GPU present: a 1-rank communicator from
+    ncclGetUniqueId / ncclCommInitRank, shard data through ncclSend -> ncclRecv on the engine's stream (loopback), and
+    the argument checks of the exchange entry point.  Exchanges between ranks need more GPUs than this box has; their
+    data path is the same pack + send/recv and is covered by the gloo tests (plan) and the virtual-shard tests (layout)."""
+    from gpu_quantum_simulator_amd import RankComm
+    n = 16
+    s = _rand_state(n, 53)
+    uid = RankComm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    with Simulator(n) as sim:
+        sim.write(s)
+        comm = RankComm(sim, 0, 1, 0, uid)
+        comm.loopback(2 << n)       # the whole shard
+        comm.loopback(1024)
+        assert np.array_equal(sim.read(), s)
+        with pytest.raises(_lib.QsimError, match="unsupported"):
+            comm.exchange([0], [3])  # a single rank has nobody to exchange with
+        assert comm.stats() == (0, 0.0, 0.0)
+        comm.close()
+    assert b"ncclSend" in subprocess.run(["nm", "-D", _lib.LIB_PATH], capture_output=True).stdout
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_virtual_shards_on_one_gpu_equal_oracle(oracle, tmp_path, world):
     """The sharded path (planner, per-rank gates, pack kernel, block exchange) with P shards on ONE device,
@@ -551,6 +649,7 @@ def test_c_host_cluster_virtual_shards(oracle, tmp_path, shards):
         assert np.max(np.abs(cl.read(12345, 7) - want[12345:12352])) < TOL  # the one-by-one path
         ex, nbytes = cl.exchange_stats()
         assert ex >= 2 and nbytes > 0
+        assert cl.exchange_mode == "direct"  # every shard on this one device: pack straight into the members' buffers
 
 
 def test_cli_sharded(oracle, golden_dir, tmp_path):

@@ -352,14 +352,25 @@ extern "C" int qsim_apply_2q(qsim_state *s, const double *U, int q_hi, int q_lo)
 }
 
 // ---- scheduling + launch -------------------------------------------------------------------------------
-static SchedConfig sched_config(int n, int fuse, int tile_bits, int tile_low_bits, int tile_max_ops, int pad_from = 10) {
+static SchedConfig sched_config(int n, int fuse, int tile_bits, int tile_low_bits, int tile_max_ops, int pad_from = 10, bool f32 = false) {
     SchedConfig c;
     c.pad_from = pad_from;
     c.n = n; c.fuse = fuse; c.tile_bits = tile_bits; c.tile_low_bits = tile_low_bits; c.tile_max_ops = tile_max_ops;
-    // The pass-set local search (SchedConfig::local_iters / lookahead; ~1.4 ms of host time per pass, hidden behind the
-    // GPU for n >= 28) brings the n = 30 bench circuit from 17 to 15 passes, but the passes it builds carry more blocks
-    // and run LDS-bound (8.9 instead of 7.8 ms each): the same 133 ms in total today, so it stays off.  QSIM_SCHED_LOCAL /
-    // QSIM_SCHED_LOOKAHEAD in the environment turn it on for experiments.
+    // The pass-set local search (SchedConfig::local_iters / lookahead) costs ~1.5 ms of host time per pass with one pass
+    // of lookahead, ~2 ms with two.  Passes are launched as they are produced, so the search is free once a pass runs
+    // longer than that on the GPU: from 4 GiB of state (n = 28 fp64: 1.9 ms per pass) with one pass of lookahead, from
+    // 16 GiB with two.  Since the row-class form of the sparse blocks (one LDS read per amplitude) most passes are
+    // bound by their memory time again, so one pass less is ~7 ms less at n = 30 (round 1: the fuller passes were
+    // LDS-bound and the total did not move).  With the search on, a pass is capped at 24 clusters (5-6 merged blocks):
+    // ~1.6 + 0.8 ms per block then stays under the pass's ~6.8 ms of memory time.  n = 30 bench circuit: 16 passes /
+    // 119.7 ms without, 15 / 114.6 ms with; n = 28: 31.1 -> 29.8 ms; n = 32: 471 -> 451 ms; n = 26 would LOSE (8.5 -> 9.9 ms,
+    // the host becomes the bottleneck), hence the threshold.  QSIM_SCHED_LOCAL / QSIM_SCHED_LOOKAHEAD override.
+    const int size_class = n - (f32 ? 1 : 0); // log2 of the state size in 16-byte units
+    if (fuse >= 3 && size_class >= 28) {
+        c.local_iters = 3;
+        c.lookahead = size_class >= 30 ? 2 : 1;
+        if (tile_max_ops == 32) c.tile_max_ops = 24; // 32 = the option's default, i.e. not chosen by the caller
+    }
     return c;
 }
 
@@ -428,7 +439,10 @@ static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, int a
         return true;
     }
     if (maxnnz > 4) return false;
-    const int T = maxnnz <= 1 ? 1 : maxnnz <= 2 ? 2 : 4;
+    // rows laid out class by class (TileBlock::classes): T rows that read the same T operand slots
+    int T = 1;
+    std::vector<std::vector<int>> crows, ccols;
+    if (!blk.classes(T, crows, ccols)) return false;
     t.kind = TOP_SP;
     t.terms = T;
     // LDS BYTE offset of a slot code (bit a of the code sits at tile-local bit b[a]), already passed through the
@@ -441,18 +455,17 @@ static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, int a
         if (amp_shift == 3) return o ^ ((0u - (hi & 1u)) & 15u);            // fp32 states keep the bit-4-only swizzle
         return o ^ (((f >> 1) & 15u) ^ ((0u - (f & 1u)) & 15u));
     };
-    for (int r = 0; r < D; r++) t.rowoff[r] = slot_off(r) << amp_shift;
     for (int v = 0; v < NB; v++)
-        for (int r = 0; r < D; r++) {
+        for (int p = 0; p < D; p++) { // position p = row crows[v][p]; its class reads the columns ccols[v][cT .. cT+T)
+            const int r = crows[v][p], c0 = (p / T) * T;
             const TileBlock::Row &row = blk.row(v, r);
-            int j = 0;
-            for (; j < row.n; j++) {
-                const int e = r * T + j;
-                t.off[v][e] = slot_off(row.col[j]) << amp_shift;
-                put(v, e, row.val[j]);
+            t.rowoff[v][p] = slot_off(r) << amp_shift;
+            for (int j = 0; j < T; j++) {
+                const int col = ccols[v][c0 + j];
+                t.off[v][p * T + j] = slot_off(col) << amp_shift;
+                put(v, p * T + j, blk.at(v, r, col)); // exact zero where the row does not use the column
             }
-            if (row.n == 1 && row.col[0] == r && is1(row.val[0])) t.meta[v] |= 1u << r; // identity row: no traffic at all
-            for (; j < T; j++) t.off[v][r * T + j] = slot_off(r) << amp_shift; // pad: zero coefficient on the row's own slot
+            if (row.n == 1 && row.col[0] == r && is1(row.val[0])) t.meta[v] |= 1u << p; // identity row
         }
     return true;
 }
@@ -545,7 +558,7 @@ extern "C" int qsim_flush(qsim_state *s) {
     if (s->tile_bits - s->tile_low_bits < 2 || s->tile_bits - s->tile_low_bits > kMaxTileHigh)
         return fail(QSIM_ERR_ARG, "tile_bits - tile_low_bits must be in 2..%d", kMaxTileHigh);
     HIP_TRY(hipSetDevice(s->device));
-    Scheduler sched(sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from));
+    Scheduler sched(sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32));
     for (const QueuedGate &g : s->queue) {
         if (g.kind == QSIM_GATE_U1) sched.add_1q(g.m, g.q0);
         else if (g.kind == QSIM_GATE_CX) sched.add_cx(g.q0, g.q1);

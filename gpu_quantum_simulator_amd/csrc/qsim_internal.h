@@ -19,17 +19,21 @@ struct M4 { double re[16], im[16]; };
 //   TOP_G1     dense 2x2 on b[0]                      re/im[bank][0..3] row-major
 //   TOP_DIAG1  diag(d0, d1) on b[0]                   re/im[bank][0..1]; meta[bank] bit 0: d0 == 1 (only the bit=1 half moves)
 //   TOP_G2     dense 4x4 on (b[1], b[0])              re/im[bank][0..15] row-major, operands held in registers
-//   TOP_SP     sparse 2^k x 2^k block, k = nq in {2..5}: every row r has `terms` (1, 2 or 4) entries
-//              y[r] = sum_j coef[r*terms + j] * x[slot_j], operands fetched straight from their LDS slots: the host
-//              stores each entry's slot as a ready LDS byte offset (wave-uniform), rows with meta[bank] bit r set are
-//              untouched (identity row) and cost nothing.  (A per-entry "coefficient is exactly 1" shortcut was
-//              measured and dropped: its wave-uniform branches serialise the LDS reads and double the scalar
-//              instruction count.)
+//   TOP_SP     sparse 2^k x 2^k block, k = nq in {2..5}, `terms` = T (1, 2 or 4) entries per row.  Per bank the block is a
+//              direct sum of small dense matrices in a permuted basis (Scheduler / TileBlock::classes), so its rows are
+//              stored CLASS by class: positions cT .. cT+T-1 are T rows that read the same T operand slots.  A class
+//              costs T LDS reads for T outputs — ONE read per amplitude whatever T is (the first version read every
+//              row's operands separately: T reads per amplitude; the block phase of a pass is LDS-bound, so that
+//              was a third of its time):
+//                  x[j] = slot off[bank][(cT)*T + j]           (taken from the class's first row: all rows carry the same list)
+//                  y[cT+i] = sum_j coef[bank][(cT+i)*T + j] * x[j]     -> written to slot rowoff[bank][cT+i]
+//              Offsets are ready LDS byte offsets (wave-uniform, layout swizzle applied).  meta[bank] bit p: position p is
+//              an identity row; a class whose T rows all are costs nothing (identity rows are packed together).
 //              Most fused clusters of Clifford+T-like circuits are permutations times phases or two independent
 //              2x2 blocks, and so are products of neighbouring ones on a few qubits (Scheduler::merge_blocks).
-//              k <= 3: one lane owns a whole group of 2^k amplitudes (reads, then writes).  k = 4, 5: the 2^k rows of a
-//              group are split over 2 or 4 lanes (8 rows each, in different waves), with a workgroup barrier between
-//              everybody's reads and the writes — the same LDS traffic per amplitude for a block that folds more gates.
+//              k <= 3: one lane owns a whole group of 2^k amplitudes (reads, then writes).  k = 4, 5: the 2^k positions of a
+//              group are split over 2 or 4 lanes (8 positions = whole classes each, in different waves), with a workgroup
+//              barrier between everybody's reads and the writes.
 //   TOP_SCALE  no qubit inside the tile: a factor per tile, applied while the tile is staged in.
 // BANKS.  A block may also depend on up to two qubits OUTSIDE the tile, provided it is block-diagonal in them (a CX
 // whose control is outside, any diagonal gate): such a qubit is constant over a tile, so it merely selects which
@@ -45,17 +49,17 @@ struct TileOp {
     int32_t kind;
     int32_t nq;           // qubits of the block inside the tile (0..5)
     int32_t b[kMaxOpQ];   // tile-local bits, ascending
-    int32_t terms;        // TOP_SP: entries per row (1, 2, 4), the same for every bank
+    int32_t terms;        // TOP_SP: T = rows per class = entries per row (1, 2, 4), the same for every bank
     int32_t nsel;         // 0..2 selecting qubits
     int32_t selbit[2];    // their global index bits, most significant bank bit first
     int32_t ident;
     uint32_t meta[kMaxBanks];
-    uint32_t rowoff[1 << kMaxOpQ];            // TOP_SP: LDS BYTE offset of row r's slot
+    uint32_t rowoff[kMaxBanks][1 << kMaxOpQ]; // TOP_SP: LDS BYTE offset of the slot position p writes (class order differs per bank)
     uint32_t off[kMaxBanks][kMaxOpEntries];   // TOP_SP: LDS BYTE offset of entry e's operand slot
     double re[kMaxBanks][kMaxOpEntries];
     double im[kMaxBanks][kMaxOpEntries];
 };
-static_assert(sizeof(TileOp) == 64 + 128 + 2048 + 8192, "TileOp layout is shared with the device");
+static_assert(sizeof(TileOp) == 64 + 4 * 128 + 2048 + 8192, "TileOp layout is shared with the device");
 
 constexpr int kMaxTileHigh = 10; // high (non-contiguous) qubits per tile
 struct TileGeom {

@@ -266,6 +266,68 @@ void TileBlock::full_matrix(cd *out) const {
             for (int j = 0; j < row(v, r).n; j++) out[(size_t)(v * d + r) * D + (v * d + row(v, r).col[j])] = row(v, r).val[j];
 }
 
+bool TileBlock::classes(int &T, std::vector<std::vector<int>> &rows, std::vector<std::vector<int>> &cols) const {
+    const int D = dim(), NB = banks();
+    struct Comp { std::vector<int> r, c; bool ident; };
+    std::vector<std::vector<Comp>> all((size_t)NB);
+    int maxsz = 1;
+    for (int v = 0; v < NB; v++) {
+        std::vector<int> parent((size_t)2 * D); // rows 0..D-1, columns D..2D-1
+        for (int i = 0; i < 2 * D; i++) parent[i] = i;
+        auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+        for (int r = 0; r < D; r++)
+            for (int j = 0; j < row(v, r).n; j++) {
+                const int a = find(r), b = find(D + row(v, r).col[j]);
+                if (a != b) parent[a] = b;
+            }
+        std::vector<int> root_of((size_t)2 * D, -1);
+        std::vector<Comp> &cs = all[v];
+        for (int r = 0; r < D; r++) {
+            const int f = find(r);
+            if (root_of[f] < 0) { root_of[f] = (int)cs.size(); cs.push_back(Comp{{}, {}, true}); }
+            Comp &cp = cs[root_of[f]];
+            cp.r.push_back(r);
+            const Row &rw = row(v, r);
+            if (!(rw.n == 1 && rw.col[0] == r && is_one(rw.val[0]))) cp.ident = false;
+        }
+        for (int c = 0; c < D; c++) {
+            const int f = find(D + c);
+            if (root_of[f] < 0) return false; // a column nobody reads: not a unitary block
+            cs[root_of[f]].c.push_back(c);
+        }
+        for (const Comp &cp : cs) {
+            if (cp.r.size() != cp.c.size() || (int)cp.r.size() > kMaxRowNnz) return false;
+            maxsz = std::max(maxsz, (int)cp.r.size());
+        }
+    }
+    T = maxsz <= 1 ? 1 : maxsz <= 2 ? 2 : 4;
+    if (D % T) return false;
+    rows.assign((size_t)NB, {});
+    cols.assign((size_t)NB, {});
+    for (int v = 0; v < NB; v++) {
+        std::vector<Comp> &cs = all[v];
+        // first-fit decreasing, identity components last so that they share classes with one another
+        std::stable_sort(cs.begin(), cs.end(), [](const Comp &a, const Comp &b) {
+            if (a.ident != b.ident) return !a.ident;
+            return a.r.size() > b.r.size();
+        });
+        std::vector<std::vector<int>> br, bc; // bins
+        for (const Comp &cp : cs) {
+            size_t k = 0;
+            while (k < br.size() && br[k].size() + cp.r.size() > (size_t)T) k++;
+            if (k == br.size()) { br.emplace_back(); bc.emplace_back(); }
+            br[k].insert(br[k].end(), cp.r.begin(), cp.r.end());
+            bc[k].insert(bc[k].end(), cp.c.begin(), cp.c.end());
+        }
+        for (size_t k = 0; k < br.size(); k++) {
+            if (br[k].size() != (size_t)T) return false; // a gap: cannot be laid out as whole classes
+            rows[v].insert(rows[v].end(), br[k].begin(), br[k].end());
+            cols[v].insert(cols[v].end(), bc[k].begin(), bc[k].end());
+        }
+    }
+    return true;
+}
+
 // Splits a fused op (1 or 2 qubits at level 3) by the tile: qubits in `inside` stay matrix indices, the others become
 // bank selectors.  The op must be block-diagonal in every qubit left outside.
 static TileBlock to_block(const FusedOp &op, uint64_t inside) {
@@ -687,6 +749,11 @@ void Scheduler::merge_blocks(std::vector<TileBlock> &blocks) const {
                             row.val[row.n++] = vals[e];
                         }
                     }
+                }
+                if (fits && k >= 2) { // one LDS trip evaluates whole row classes (TileBlock::classes): the product must have them
+                    int T;
+                    std::vector<std::vector<int>> cr, cc;
+                    fits = m.classes(T, cr, cc);
                 }
                 if (fits) {
                     for (int v = 0; v < (1 << nss); v++) // keep every row's entries in ascending column order

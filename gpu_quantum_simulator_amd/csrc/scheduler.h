@@ -82,6 +82,15 @@ struct TileBlock {
     // the block as ONE matrix on the qubits (s..., q...), most significant first: block-diagonal in the bank index.
     // `out` holds (1 << (ns + nq))^2 entries.
     void full_matrix(cd *out) const;
+    // Row classes (what one LDS trip of k_tile evaluates with ONE read per amplitude).  Per bank the nonzero pattern of a
+    // block splits into connected components of rows and columns; in every block built from 1- and 2-qubit gates under
+    // the kMaxRowNnz limit a component has as many columns as rows, at most kMaxRowNnz of each — the block is a direct
+    // sum of small dense matrices in a permuted basis.  classes() packs the components of each bank into classes of
+    // exactly T rows sharing exactly T columns (T = 1, 2 or 4, the same for all banks): rows[v] lists the rows class by
+    // class, cols[v] the columns of class c at [c*T, (c+1)*T).  Identity rows are packed together so that whole classes
+    // can be skipped.  false: some component is larger than kMaxRowNnz or the packing leaves a gap (such a block is
+    // never built: merge_blocks asks first).
+    bool classes(int &T, std::vector<std::vector<int>> &rows, std::vector<std::vector<int>> &cols) const;
 };
 
 struct Pass {

@@ -62,6 +62,10 @@ def parse_args(argv=None):
     ap.add_argument("--sizes", default="24,28,32",
                     help="other register sizes measured after the headline run and reported under `sizes` ('' = none)")
     ap.add_argument("--size-steps", type=int, default=3)
+    ap.add_argument("--no-tune", action="store_true",
+                    help="skip the geometry planning step (qsim_tune_circuit) and run every pass with its tile bits in ascending order")
+    ap.add_argument("--tune-candidates", type=int, default=48)
+    ap.add_argument("--tune-ms", type=float, default=8000.0, help="wall-time budget of the planning step per register size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args(argv)
@@ -233,6 +237,19 @@ class Bench:
                 sim.run(circuit)
                 sim.flush()
 
+        # Planning, outside the timed region (like parsing): one untuned step is timed for the record, then every pass of
+        # the schedule is measured under candidate orders of its tile bits and the best order per geometry is kept
+        # (qsim_tune_circuit).  Same passes, same blocks, same results — only the walk order changes.
+        tuning = None
+        if dist is None and probe_q is None and not args.no_tune and fuse >= 3:
+            run_step()
+            self.fence(sim)
+            t0 = time.perf_counter()
+            run_step()
+            self.fence(sim)
+            untuned_ms = 1e3 * (time.perf_counter() - t0)
+            tuning = sim.tune(circuit, args.tune_candidates, args.tune_ms)
+            tuning["untuned_ms_per_step"] = untuned_ms
         for _ in range(warmup):
             run_step()
         self.fence(sim)
@@ -268,7 +285,7 @@ class Bench:
                 probe[f"q{q}"] = {"kernel": name, "achieved": gbs, "frac": gbs / HBM_PEAK_GBPS, "avg_launch_ms": k[name]["ms"] / 6}
 
         res = {"workload": workload, "n": n, "gates": gates, "elapsed": elapsed, "steps": steps, "stats": stats,
-               "norm2": norm2, "probe": probe, "fuse": fuse}
+               "norm2": norm2, "probe": probe, "fuse": fuse, "tuning": tuning}
         if dist is not None:
             xs, xb = sim.exchange_seconds / steps, sim.exchange_bytes / steps
             res["exchange"] = {"per_step": sim.plan.exchanges,
@@ -351,6 +368,7 @@ def main():
             "norm2": head["norm2"],
             "roofline": roof,
             "roofline_1q_probe": head["probe"],
+            "geometry_planning": head["tuning"],
         }
         if "exchange" in head:
             out["exchange"] = head["exchange"]
@@ -367,6 +385,7 @@ def main():
                        "value": args.depth * r["steps"] / r["elapsed"], "unit": "gate-applies/s",
                        "ms_per_step": 1e3 * r["elapsed"] / r["steps"], "steps": r["steps"],
                        "launches_per_step": r["stats"]["launches"] / r["steps"], "norm2": r["norm2"],
+                       "geometry_planning": r["tuning"],
                        "roofline": None if rf is None else {k: rf[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms")}}
                 if "exchange" in r:
                     row["exchange"] = r["exchange"]

@@ -16,6 +16,7 @@ OPT_FUSE, OPT_PROFILE, OPT_TILE_BITS, OPT_TILE_LOW_BITS, OPT_MAX_PENDING, OPT_TI
 OPT_TILE_PAD_FROM = 9
 OPT_DEBUG_SKIP_OPS = 10
 OPT_DEBUG_SKIP_MEM = 11
+OPT_DEBUG_TILE_ORDER = 12
 K_NAMES = ("init", "gate1", "gate1_lo", "phase", "cx", "gate2", "tile", "pack")
 K_COUNT = len(K_NAMES)
 
@@ -29,6 +30,14 @@ class QsimStats(ctypes.Structure):
                 "algorithmic_bytes": float(self.algorithmic_bytes),
                 "kernels": {K_NAMES[k]: {"launches": int(self.k_launches[k]), "bytes": float(self.k_bytes[k]),
                                          "ms": float(self.k_ms[k])} for k in range(K_COUNT)}}
+
+
+class QsimTuneReport(ctypes.Structure):
+    _fields_ = [("tile_passes", c_int), ("already_known", c_int), ("passes_tuned", c_int), ("passes_reordered", c_int),
+                ("candidates_timed", c_int), ("ms_ascending", c_double), ("ms_best", c_double), ("seconds", c_double)]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 SCHED_CB = ctypes.CFUNCTYPE(None, c_void_p, c_int, c_int, c_int, POINTER(c_int), c_int, POINTER(c_double), c_int)
@@ -101,6 +110,10 @@ SIGNATURES = {
     "qsim_get_stats": (c_int, [c_void_p, POINTER(QsimStats)]),
     "qsim_reset_stats": (c_int, [c_void_p]),
     "qsim_launch_log": (c_long, [c_void_p, c_long, POINTER(c_int), POINTER(c_int), POINTER(c_uint64), POINTER(c_double)]),
+    "qsim_launch_log_order": (c_int, [c_void_p, c_long, POINTER(c_int), POINTER(c_int)]),
+    "qsim_tune_circuit": (c_int, [c_void_p, c_void_p, c_int, c_double, POINTER(QsimTuneReport)]),
+    "qsim_tune_table_size": (c_long, []),
+    "qsim_tune_table_clear": (None, []),
     "qsim_circuit_parse_file": (c_int, [c_char_p, POINTER(c_void_p)]),
     "qsim_circuit_parse_text": (c_int, [c_char_p, c_size_t, POINTER(c_void_p)]),
     "qsim_circuit_create": (c_int, [c_int, POINTER(c_void_p)]),

@@ -3,6 +3,12 @@
 //
 // There is no CPU execution path in this file or anywhere in libqsim.so: if the HIP runtime reports no
 // usable device, qsim_create() fails with QSIM_ERR_DEVICE.
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -65,8 +71,9 @@ struct ProfEvent {
     int kclass;
     int n_ops;
     uint64_t high_mask;
+    uint64_t order_code; // tile passes: the high tile bits in tile-local order, 5 bits each, lowest first
 };
-struct LaunchRec { int kclass, n_ops; uint64_t high_mask; double ms; };
+struct LaunchRec { int kclass, n_ops; uint64_t high_mask; double ms; uint64_t order_code; };
 
 struct qsim_state {
     int n = 0, device = 0;
@@ -76,7 +83,8 @@ struct qsim_state {
     bool owns = false;
     size_t amp_bytes() const { return f32 ? 8 : 16; }
     // options
-    int fuse = 3, profile = 0, tile_bits = 12, tile_low_bits = 3, tile_max_ops = 32, grid_cap = 0, tile_threads = 0, tile_pad_from = 10, debug_skip_ops = 0, debug_skip_mem = 0;
+    int fuse = 3, profile = 0, tile_bits = 12, tile_low_bits = 3, tile_max_ops = 32, grid_cap = 0, tile_threads = 0, tile_pad_from = 10, debug_skip_ops = 0, debug_skip_mem = 0, debug_tile_order = 0;
+    uint64_t tile_passes = 0; // launched so far (seeds the probe permutations of QSIM_OPT_DEBUG_TILE_ORDER)
     long max_pending = 1L << 16;
     // queue
     std::vector<QueuedGate> queue;
@@ -203,6 +211,9 @@ extern "C" int qsim_set_option(qsim_state *s, int option, long value) {
     case QSIM_OPT_DEBUG_SKIP_MEM:
         s->debug_skip_mem = value != 0;
         break;
+    case QSIM_OPT_DEBUG_TILE_ORDER:
+        s->debug_tile_order = (int)value;
+        break;
 
     case QSIM_OPT_TILE_THREADS:
         if (value != 0 && value != 256 && value != 512 && value != 1024)
@@ -228,6 +239,7 @@ extern "C" long qsim_get_option(const qsim_state *s, int option) {
     case QSIM_OPT_TILE_PAD_FROM: return s->tile_pad_from;
     case QSIM_OPT_DEBUG_SKIP_OPS: return s->debug_skip_ops;
     case QSIM_OPT_DEBUG_SKIP_MEM: return s->debug_skip_mem;
+    case QSIM_OPT_DEBUG_TILE_ORDER: return s->debug_tile_order;
     default: return -1;
     }
 }
@@ -250,7 +262,7 @@ static int resolve_events(qsim_state *s) {
     for (auto &pe : s->events) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) s->stats.k_ms[pe.kclass] += ms;
-        if (s->launch_log.size() < (1u << 20)) s->launch_log.push_back({pe.kclass, pe.n_ops, pe.high_mask, (double)ms});
+        if (s->launch_log.size() < (1u << 20)) s->launch_log.push_back({pe.kclass, pe.n_ops, pe.high_mask, (double)ms, pe.order_code});
         s->event_pool.push_back(pe.start);
         s->event_pool.push_back(pe.stop);
     }
@@ -262,11 +274,12 @@ struct LaunchScope { // records a start/stop pair around one launch when profili
     qsim_state *s;
     ProfEvent pe{};
     bool on;
-    LaunchScope(qsim_state *st, int kclass, int n_ops = 1, uint64_t high_mask = 0) : s(st), on(st->profile != 0) {
+    LaunchScope(qsim_state *st, int kclass, int n_ops = 1, uint64_t high_mask = 0, uint64_t order_code = 0) : s(st), on(st->profile != 0) {
         if (on) {
             pe.kclass = kclass;
             pe.n_ops = n_ops;
             pe.high_mask = high_mask;
+            pe.order_code = order_code;
             pe.start = take_event(s);
             pe.stop = take_event(s);
             (void)hipEventRecord(pe.start, s->stream);
@@ -356,19 +369,20 @@ static SchedConfig sched_config(int n, int fuse, int tile_bits, int tile_low_bit
     SchedConfig c;
     c.pad_from = pad_from;
     c.n = n; c.fuse = fuse; c.tile_bits = tile_bits; c.tile_low_bits = tile_low_bits; c.tile_max_ops = tile_max_ops;
-    // The pass-set local search (SchedConfig::local_iters / lookahead) costs ~1.5 ms of host time per pass with one pass
-    // of lookahead, ~2 ms with two.  Passes are launched as they are produced, so the search is free once a pass runs
-    // longer than that on the GPU: from 4 GiB of state (n = 28 fp64: 1.9 ms per pass) with one pass of lookahead, from
-    // 16 GiB with two.  Since the row-class form of the sparse blocks (one LDS read per amplitude) most passes are
-    // bound by their memory time again, so one pass less is ~7 ms less at n = 30 (round 1: the fuller passes were
-    // LDS-bound and the total did not move).  With the search on, a pass is capped at 24 clusters (5-6 merged blocks):
-    // ~1.6 + 0.8 ms per block then stays under the pass's ~6.8 ms of memory time.  n = 30 bench circuit: 16 passes /
-    // 119.7 ms without, 15 / 114.6 ms with; n = 28: 31.1 -> 29.8 ms; n = 32: 471 -> 451 ms; n = 26 would LOSE (8.5 -> 9.9 ms,
+    // The pass-set local search (SchedConfig::local_iters with one pass of lookahead) costs ~1.5 ms of host time per
+    // pass.  Passes are launched as they are produced, so the search is free once a pass runs longer than that on the
+    // GPU: from 4 GiB of state (n = 28 fp64: 1.9 ms per pass).  Since the row-class form of the sparse blocks (one LDS
+    // read per amplitude) most passes are bound by their memory time again, so one pass less is ~7 ms less at n = 30
+    // (round 1: the fuller passes were LDS-bound and the total did not move).  With the search on, a pass is capped at
+    // 24 clusters (5-6 merged blocks): ~1.6 + 0.8 ms per block then stays under the pass's ~6.8 ms of memory time.
+    // Twelve seeded 1000-gate circuits at n = 30: 204 passes without the search, 188 with it (191 / 193 with two /
+    // three passes of lookahead, which also cost more host time, so one it is).  n = 30 bench circuit: 16 passes /
+    // 119.7 ms without, 15 / 115.5 ms with; n = 28: 31.1 -> 29.8 ms; n = 32: 471 -> 451 ms; n = 26 would LOSE (8.5 -> 9.9 ms,
     // the host becomes the bottleneck), hence the threshold.  QSIM_SCHED_LOCAL / QSIM_SCHED_LOOKAHEAD override.
     const int size_class = n - (f32 ? 1 : 0); // log2 of the state size in 16-byte units
     if (fuse >= 3 && size_class >= 28) {
         c.local_iters = 3;
-        c.lookahead = size_class >= 30 ? 2 : 1;
+        c.lookahead = 1;
         if (tile_max_ops == 32) c.tile_max_ops = 24; // 32 = the option's default, i.e. not chosen by the caller
     }
     return c;
@@ -401,11 +415,17 @@ static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, int a
         if (local_bit(g, blk.s[a]) >= 0 || blk.s[a] < 0 || blk.s[a] >= g.n) return false; // selectors lie outside the tile
         t.selbit[a] = blk.s[a];
     }
+    // qbit[a]: tile-local bit of the block's a-th qubit in ascending GLOBAL order = bit a of a row / column index.
+    // t.b[]: the same bits sorted ascending — what the kernel inserts zeros at to enumerate the block's groups.  The two
+    // orders agree while TileGeom::high is ascending and differ once the engine reorders the tile bits.
+    int qbit[kMaxOpQ] = {0, 0, 0, 0, 0};
     for (int a = 0; a < k; a++) {
-        const int lb = local_bit(g, blk.q[k - 1 - a]); // ascending
+        const int lb = local_bit(g, blk.q[k - 1 - a]);
         if (lb < 0) return false;
+        qbit[a] = lb;
         t.b[a] = lb;
     }
+    std::sort(t.b, t.b + k);
     auto is1 = [&](const cd &z) { return z.real() == 1.0 && z.imag() == 0.0; };
     auto put = [&](int v, int e, const cd &z) { t.re[v][e] = z.real(); t.im[v][e] = z.imag(); };
     for (int v = 0; v < NB; v++)
@@ -433,9 +453,11 @@ static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, int a
         return true;
     }
     if (k == 2 && maxnnz > 2) { // dense 4x4: register form
-        t.kind = TOP_G2;
+        t.kind = TOP_G2; // the kernel's index bit 0 is t.b[0], bit 1 is t.b[1]: swap the qubits' roles if the tile order did
+        const bool swapped = qbit[0] > qbit[1];
+        auto sw = [&](int i) { return swapped ? ((i & 1) << 1) | (i >> 1) : i; };
         for (int v = 0; v < NB; v++)
-            for (int e = 0; e < 16; e++) put(v, e, blk.at(v, e >> 2, e & 3));
+            for (int e = 0; e < 16; e++) put(v, e, blk.at(v, sw(e >> 2), sw(e & 3)));
         return true;
     }
     if (maxnnz > 4) return false;
@@ -450,7 +472,7 @@ static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, int a
     // linear, so it commutes with the XOR the kernel combines it with)
     auto slot_off = [&](int code) {
         uint32_t o = 0;
-        for (int a = 0; a < k; a++) o |= (uint32_t)((code >> a) & 1) << t.b[a];
+        for (int a = 0; a < k; a++) o |= (uint32_t)((code >> a) & 1) << qbit[a];
         const uint32_t hi = o >> 4, f = (hi ^ (hi >> 5) ^ (hi >> 10)) & 31u; // = sw_fold of kernels_impl.inc
         if (amp_shift == 3) return o ^ ((0u - (hi & 1u)) & 15u);            // fp32 states keep the bit-4-only swizzle
         return o ^ (((f >> 1) & 15u) ^ ((0u - (f & 1u)) & 15u));
@@ -468,6 +490,92 @@ static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, int a
             if (row.n == 1 && row.col[0] == r && is1(row.val[0])) t.meta[v] |= 1u << p; // identity row
         }
     return true;
+}
+
+// Which role each high tile bit plays.  Tile-local bit L+j is global bit high[j], in ANY order (the blocks address LDS
+// by tile-local bit and are translated through local_bit(), so the order is invisible to them); with 2^L <= 8 amplitudes
+// per run and 512 threads, high[0..2] are walked by the lanes of a wave (the 8 runs one load instruction touches),
+// high[3..5] by the waves of the workgroup, high[6..8] by the 8 registers of a lane.  The memory-only time of a pass
+// depends on this order as much as on the set itself (n = 30, tools/geom_probe4.py: one set 6.56 ... 9.05 ms over 48
+// random orders, ascending 7.67; another 8.40 ... 14.05, ascending 14.06) and no simple rule predicts it (a boosted-tree
+// model on 3000 samples explains a third of the variance), so it is MEASURED: qsim_tune_circuit times candidate
+// orders for every pass of a circuit's schedule and keeps the best in a process-wide table keyed by (register size,
+// precision, tile shape, bit set) — planning in the sense of FFTW's wisdom, outside any timed region.  Untuned passes
+// walk their bits in ascending order (what the scheduler emits).  QSIM_OPT_DEBUG_TILE_ORDER = k > 0 shuffles every
+// pass's order with a generator seeded by k and the pass count instead (probes, and the parity tests of the reordering).
+struct GeomKey {
+    int n, f32, tile_bits, low_bits;
+    uint64_t high_mask;
+    bool operator<(const GeomKey &o) const {
+        return std::tie(n, f32, tile_bits, low_bits, high_mask) < std::tie(o.n, o.f32, o.tile_bits, o.low_bits, o.high_mask);
+    }
+};
+struct GeomOrder { int8_t high[kMaxTileHigh]; float ms, ms_ascending; };
+static std::mutex g_wisdom_mu;
+static std::map<GeomKey, GeomOrder> g_wisdom;
+
+static GeomKey geom_key(const qsim_state *s, const TileGeom &g) {
+    GeomKey k{g.n, s->f32 ? 1 : 0, g.tile_bits, g.low_bits, 0};
+    for (int j = 0; j < g.n_high; j++) k.high_mask |= 1ULL << g.high[j];
+    return k;
+}
+
+static void shuffle_high(TileGeom &g, uint64_t seed) {
+    uint64_t x = seed | 1ULL;
+    for (int i = g.n_high - 1; i > 0; i--) { // Fisher-Yates with xorshift64*
+        x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+        const int j = (int)(((x * 0x2545F4914F6CDD1DULL) >> 33) % (uint64_t)(i + 1));
+        std::swap(g.high[i], g.high[j]);
+    }
+}
+
+static void order_tile_bits(qsim_state *s, TileGeom &g) {
+    s->tile_passes++;
+    if (g.n_high < 2) return;
+    if (s->debug_tile_order > 0) {
+        shuffle_high(g, 0x9E3779B97F4A7C15ULL * (uint64_t)(s->debug_tile_order + 1) + 0xD1B54A32D192ED03ULL * s->tile_passes);
+        return;
+    }
+    std::lock_guard<std::mutex> lock(g_wisdom_mu);
+    auto it = g_wisdom.find(geom_key(s, g));
+    if (it != g_wisdom.end())
+        for (int j = 0; j < g.n_high; j++) g.high[j] = it->second.high[j];
+}
+
+// Uploads the blocks of a tile pass for the given bit order and launches it (no statistics, no profiling events).
+static int launch_tile_pass(qsim_state *s, const Pass &p, const TileGeom &geom, bool from_zero_ket) {
+    const size_t need = p.blocks.size();
+    if (need > s->ops_cap) return fail(QSIM_ERR_ARG, "tile pass with %zu ops exceeds the op buffer", need);
+    if (s->ops_used + need > s->ops_cap) { // ring is full: wait until earlier passes have read their ops
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        s->ops_used = 0;
+    }
+    TileOp *h = s->h_ops + s->ops_used;
+    for (size_t k = 0; k < need; k++)
+        if (!to_tile_op(geom, p.blocks[k], h[k], s->f32 ? 3 : 4)) return fail(QSIM_ERR_ARG, "internal: block does not fit its tile pass");
+    if (s->f32) // the fp32 kernels read float coefficients from the front of each bank's re[] / im[] (rounded once, here)
+        for (size_t k = 0; k < need; k++)
+            for (int v = 0; v < kMaxBanks; v++) {
+                float fr[kMaxOpEntries], fi[kMaxOpEntries];
+                for (int e = 0; e < kMaxOpEntries; e++) { fr[e] = (float)h[k].re[v][e]; fi[e] = (float)h[k].im[v][e]; }
+                memcpy(h[k].re[v], fr, sizeof fr);
+                memcpy(h[k].im[v], fi, sizeof fi);
+            }
+    TileOp *d = s->d_ops + s->ops_used;
+    HIP_TRY(hipMemcpyAsync(d, h, need * sizeof(TileOp), hipMemcpyHostToDevice, s->stream));
+    s->ops_used += need;
+    LaunchCfg cfg{s->stream, s->grid_cap};
+    const int threads = s->tile_threads; // 0: default for the tile size
+    hipError_t e;
+    if (s->debug_skip_ops) {
+        TileGeom bare = geom;
+        bare.n_scale = 0;
+        e = launch_tile(cfg, s->amps, s->f32, bare, d, 0, threads, from_zero_ket, s->zero_ket_amp);
+    } else {
+        e = launch_tile(cfg, s->amps, s->f32, geom, d, (int)need, threads, from_zero_ket, s->zero_ket_amp, s->debug_skip_mem != 0);
+    }
+    if (e != hipSuccess) return fail(QSIM_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+    return QSIM_OK;
 }
 
 static int launch_pass(qsim_state *s, const Pass &p) {
@@ -511,37 +619,13 @@ static int launch_pass(qsim_state *s, const Pass &p) {
         break;
     }
     case QSIM_K_TILE: {
-        const size_t need = p.blocks.size();
-        if (need > s->ops_cap) return fail(QSIM_ERR_ARG, "tile pass with %zu ops exceeds the op buffer", need);
-        if (s->ops_used + need > s->ops_cap) { // ring is full: wait until earlier passes have read their ops
-            HIP_TRY(hipStreamSynchronize(s->stream));
-            s->ops_used = 0;
-        }
-        TileOp *h = s->h_ops + s->ops_used;
-        for (size_t k = 0; k < need; k++)
-            if (!to_tile_op(p.geom, p.blocks[k], h[k], s->f32 ? 3 : 4)) return fail(QSIM_ERR_ARG, "internal: block does not fit its tile pass");
-        if (s->f32) // the fp32 kernels read float coefficients from the front of each bank's re[] / im[] (rounded once, here)
-            for (size_t k = 0; k < need; k++)
-                for (int v = 0; v < kMaxBanks; v++) {
-                    float fr[kMaxOpEntries], fi[kMaxOpEntries];
-                    for (int e = 0; e < kMaxOpEntries; e++) { fr[e] = (float)h[k].re[v][e]; fi[e] = (float)h[k].im[v][e]; }
-                    memcpy(h[k].re[v], fr, sizeof fr);
-                    memcpy(h[k].im[v], fi, sizeof fi);
-                }
-        TileOp *d = s->d_ops + s->ops_used;
-        HIP_TRY(hipMemcpyAsync(d, h, need * sizeof(TileOp), hipMemcpyHostToDevice, s->stream));
-        s->ops_used += need;
-        uint64_t hm = 0;
-        for (int j = 0; j < p.geom.n_high; j++) hm |= 1ULL << p.geom.high[j];
-        LaunchScope scope(s, p.kclass, (int)need, hm);
-        const int threads = s->tile_threads; // 0: default for the tile size
-        if (s->debug_skip_ops) {
-            TileGeom bare = p.geom;
-            bare.n_scale = 0;
-            e = launch_tile(cfg, s->amps, s->f32, bare, d, 0, threads, from_zero_ket, s->zero_ket_amp);
-        } else {
-            e = launch_tile(cfg, s->amps, s->f32, p.geom, d, (int)need, threads, from_zero_ket, s->zero_ket_amp, s->debug_skip_mem != 0);
-        }
+        TileGeom geom = p.geom;
+        order_tile_bits(s, geom);
+        uint64_t hm = 0, oc = 0;
+        for (int j = 0; j < geom.n_high; j++) { hm |= 1ULL << geom.high[j]; oc |= (uint64_t)geom.high[j] << (5 * j); }
+        LaunchScope scope(s, p.kclass, (int)p.blocks.size(), hm, oc);
+        const int rc = launch_tile_pass(s, p, geom, from_zero_ket);
+        if (rc) return rc;
         break;
     }
     default: return fail(QSIM_ERR_ARG, "internal: unknown kernel class %d", p.kclass);
@@ -835,6 +919,17 @@ extern "C" int qsim_reset_stats(qsim_state *s) {
     return QSIM_OK;
 }
 
+extern "C" int qsim_launch_log_order(qsim_state *s, long index, int *order, int *count) {
+    if (!s || !order || !count) return QSIM_ERR_ARG;
+    if (resolve_events(s)) return QSIM_ERR_DEVICE;
+    if (index < 0 || index >= (long)s->launch_log.size()) return QSIM_ERR_ARG;
+    const LaunchRec &r = s->launch_log[index];
+    const int n = __builtin_popcountll(r.high_mask);
+    for (int j = 0; j < n; j++) order[j] = (int)((r.order_code >> (5 * j)) & 31u);
+    *count = r.kclass == QSIM_K_TILE ? n : 0;
+    return QSIM_OK;
+}
+
 extern "C" long qsim_launch_log(qsim_state *s, long index, int *kclass, int *n_ops, uint64_t *high_mask, double *ms) {
     if (!s) return -1;
     if (resolve_events(s)) return -1;
@@ -882,6 +977,111 @@ static void feed(Scheduler &sched, const qsim_circuit *c) {
             sched.add_2q(m, g.q0, g.q1);
         }
     }
+}
+
+// ---- measured pass geometry -------------------------------------------------------------------------------------------
+// Plans the circuit exactly as qsim_run_circuit + qsim_flush would and, for every tile pass whose geometry is not in the
+// table yet, times the pass (its real blocks, on whatever the state buffer holds) under candidate orders of its high
+// tile bits: ascending first, then pseudo-random permutations seeded by the bit set, until max_candidates have been
+// tried or the pass's share of budget_ms is spent (at least four).  The fastest order goes into the process-wide table
+// order_tile_bits() consults.  The state's contents are clobbered, so it is left reset to |0...0>.  Results never
+// depend on the order; only the pass times do.
+extern "C" int qsim_tune_circuit(qsim_state *s, const qsim_circuit *c, int max_candidates, double budget_ms, qsim_tune_report *rep) {
+    if (!s || !c) return fail(QSIM_ERR_ARG, "NULL argument");
+    if (c->num_q != s->n) return fail(QSIM_ERR_ARG, "circuit has %d qubits, state has %d", c->num_q, s->n);
+    if (max_candidates < 1) max_candidates = 1;
+    int rc = qsim_sync(s);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    Scheduler sched(sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32));
+    feed(sched, c);
+    std::vector<Pass> passes;
+    sched.finish(passes);
+    qsim_tune_report r{};
+    std::vector<const Pass *> todo;
+    for (const Pass &p : passes) {
+        if (p.kclass != QSIM_K_TILE) continue;
+        r.tile_passes++;
+        if (p.geom.n_high < 2) continue;
+        std::lock_guard<std::mutex> lock(g_wisdom_mu);
+        if (g_wisdom.count(geom_key(s, p.geom))) { r.already_known++; continue; }
+        bool dup = false;
+        for (const Pass *q : todo) dup = dup || (geom_key(s, q->geom).high_mask == geom_key(s, p.geom).high_mask);
+        if (!dup) todo.push_back(&p);
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto elapsed_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    const int saved_skip_mem = s->debug_skip_mem;
+    s->debug_skip_mem = 0;
+    auto timed = [&](const Pass &p, const TileGeom &g, float &ms) -> int {
+        (void)hipEventRecord(e0, s->stream);
+        const int rc2 = launch_tile_pass(s, p, g, false);
+        if (rc2) return rc2;
+        (void)hipEventRecord(e1, s->stream);
+        if (hipEventSynchronize(e1) != hipSuccess) return fail(QSIM_ERR_DEVICE, "tuning: event sync failed");
+        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return fail(QSIM_ERR_DEVICE, "tuning: event time failed");
+        return QSIM_OK;
+    };
+    rc = QSIM_OK;
+    for (size_t i = 0; i < todo.size() && rc == QSIM_OK; i++) {
+        const Pass &p = *todo[i];
+        const double share_end = budget_ms > 0 ? budget_ms * (double)(i + 1) / (double)todo.size() : 1e300;
+        TileGeom asc = p.geom;
+        std::sort(asc.high, asc.high + asc.n_high);
+        float ms = 0.f;
+        rc = timed(p, asc, ms); // warm: first touch of the op buffer and of this geometry's code path
+        if (rc == QSIM_OK) rc = timed(p, asc, ms);
+        if (rc) break;
+        GeomOrder best{};
+        for (int j = 0; j < asc.n_high; j++) best.high[j] = (int8_t)asc.high[j];
+        best.ms = best.ms_ascending = ms;
+        const GeomKey key = geom_key(s, asc);
+        for (int cand = 1; cand < max_candidates; cand++) {
+            if (cand >= 4 && elapsed_ms() > share_end) break;
+            TileGeom g = asc;
+            shuffle_high(g, key.high_mask * 0x9E3779B97F4A7C15ULL + (uint64_t)cand * 0xD1B54A32D192ED03ULL);
+            rc = timed(p, g, ms);
+            if (rc) break;
+            r.candidates_timed++;
+            if (ms < best.ms) {
+                best.ms = ms;
+                for (int j = 0; j < g.n_high; j++) best.high[j] = (int8_t)g.high[j];
+            }
+        }
+        if (rc) break;
+        if (best.ms < best.ms_ascending * 0.985f) { // keep ascending unless the gain is beyond the timing noise
+            r.passes_reordered++;
+        } else {
+            for (int j = 0; j < asc.n_high; j++) best.high[j] = (int8_t)asc.high[j];
+            best.ms = best.ms_ascending;
+        }
+        r.ms_ascending += best.ms_ascending;
+        r.ms_best += best.ms;
+        r.passes_tuned++;
+        std::lock_guard<std::mutex> lock(g_wisdom_mu);
+        g_wisdom[key] = best;
+    }
+    s->debug_skip_mem = saved_skip_mem;
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    r.seconds = elapsed_ms() * 1e-3;
+    if (rep) *rep = r;
+    const int rc_reset = qsim_reset(s);
+    return rc ? rc : rc_reset;
+}
+
+extern "C" long qsim_tune_table_size(void) {
+    std::lock_guard<std::mutex> lock(g_wisdom_mu);
+    return (long)g_wisdom.size();
+}
+
+extern "C" void qsim_tune_table_clear(void) {
+    std::lock_guard<std::mutex> lock(g_wisdom_mu);
+    g_wisdom.clear();
 }
 
 extern "C" int qsim_plan_circuit(const qsim_circuit *c, int fuse, int tile_bits, int tile_low_bits, qsim_stats *out) {

@@ -67,7 +67,7 @@ struct TileGeom {
     int32_t low_bits;           // L: tile-local bits [0,L) are global bits [0,L)
     int32_t n_high;             // B - L
     int32_t n;                  // qubits in this state (shard)
-    int32_t high[kMaxTileHigh]; // ascending global bit of tile-local bit L+j
+    int32_t high[kMaxTileHigh]; // global bit of tile-local bit L+j; any order (the scheduler emits ascending, the engine may reorder)
     int32_t n_scale;            // leading entries of the pass's op list that are TOP_SCALE factors, not blocks
 };
 

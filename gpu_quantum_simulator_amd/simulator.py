@@ -162,7 +162,7 @@ class Simulator:
                  "max_pending": _lib.OPT_MAX_PENDING, "tile_max_ops": _lib.OPT_TILE_MAX_OPS,
                  "grid_cap": _lib.OPT_GRID_CAP, "tile_threads": _lib.OPT_TILE_THREADS,
                  "tile_pad_from": _lib.OPT_TILE_PAD_FROM, "debug_skip_ops": _lib.OPT_DEBUG_SKIP_OPS,
-                 "debug_skip_mem": _lib.OPT_DEBUG_SKIP_MEM}
+                 "debug_skip_mem": _lib.OPT_DEBUG_SKIP_MEM, "debug_tile_order": _lib.OPT_DEBUG_TILE_ORDER}
         # tile_low_bits first when shrinking, tile_bits first when growing: keep every intermediate valid
         for key in sorted(options, key=lambda k: k != "tile_low_bits"):
             self.set_option(names[key], options[key])
@@ -206,6 +206,13 @@ class Simulator:
 
     def flush(self) -> None:
         check(_lib.load().qsim_flush(self._h))
+
+    def tune(self, circuit: Circuit, max_candidates: int = 32, budget_ms: float = 6000.0) -> dict:
+        """qsim_tune_circuit: times every pass of the circuit's schedule under candidate orders of its tile bits and
+        keeps the fastest per geometry in the library's process-wide table (planning; leaves the state reset)."""
+        rep = _lib.QsimTuneReport()
+        check(_lib.load().qsim_tune_circuit(self._h, circuit._h, max_candidates, budget_ms, byref(rep)))
+        return rep.as_dict()
 
     def pack_bits_to(self, bits: Sequence[int], dst_ptrs: Sequence[int]) -> None:
         """qsim_pack_bits_to: block b of the packed layout goes to dst_ptrs[b]."""
@@ -289,6 +296,17 @@ class Simulator:
             k, o, hm, ms = c_int(), c_int(), c_uint64(), c_double()
             lib.qsim_launch_log(self._h, i, byref(k), byref(o), byref(hm), byref(ms))
             out.append((_lib.K_NAMES[k.value], o.value, hm.value, ms.value))
+        return out
+
+    def launch_log_orders(self) -> list:
+        """Per launch since reset_stats: the tile pass's high tile bits in tile-local order ([] for other kernels)."""
+        lib = _lib.load()
+        n = lib.qsim_launch_log(self._h, -1, None, None, None, None)
+        out = []
+        for i in range(max(n, 0)):
+            order, cnt = (c_int * 10)(), c_int()
+            check(lib.qsim_launch_log_order(self._h, i, order, byref(cnt)))
+            out.append([order[j] for j in range(cnt.value)])
         return out
 
     def reset_stats(self) -> None:

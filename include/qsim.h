@@ -61,6 +61,9 @@ enum {
     QSIM_OPT_TILE_THREADS = 8, /* threads per tile workgroup: 0 auto (256 below 2^12 amplitudes, else 512), 256, 512, 1024 */
     QSIM_OPT_DEBUG_SKIP_OPS = 10,/* measurement aid, default 0: 1 = tile passes move their tiles HBM -> LDS -> HBM but apply
                                   * no blocks (amplitudes are then WRONG); splits a pass's memory time from its compute time */
+    QSIM_OPT_DEBUG_TILE_ORDER = 12,/* measurement aid, default 0: k > 0 = every tile pass walks its high tile bits in a pseudo-random
+                                  * order seeded by k (results are unchanged: the order only decides which bits lanes, waves and
+                                  * registers walk) */
     QSIM_OPT_DEBUG_SKIP_MEM = 11 /* measurement aid, default 0: 1 = tile passes apply their blocks to zero-filled tiles and
                                   * neither load nor store the state (amplitudes are then WRONG): the block phase alone */
 };
@@ -246,6 +249,32 @@ int qsim_reset_stats(qsim_state *s);
  * for 0 <= index < count, fills the kernel class, the fused blocks in that launch, the tile's high-qubit
  * mask and the HIP-event time. */
 long qsim_launch_log(qsim_state *s, long index, int *kernel_class, int *n_ops, uint64_t *high_mask, double *ms);
+/* For a tile pass of the launch log: its high tile bits in tile-local order (order[j] = global bit of tile-local bit L+j;
+ * the first three are walked by the lanes of a wave, the next by its waves, the last by a lane's registers); count = 0
+ * for other kernels.  order needs room for 10 entries. */
+int qsim_launch_log_order(qsim_state *s, long index, int *order, int *count);
+
+/* ---- measured pass geometry (planning, in the sense of FFTW's wisdom) -------------------------------------------------
+ * A cache-blocked pass walks nine "high" index bits besides the contiguous low ones; which of them the lanes of a wave,
+ * the waves of a workgroup and the registers of a lane walk changes nothing in the result and up to 2x in the pass's
+ * HBM time.  qsim_tune_circuit plans `circuit` as qsim_run_circuit would and times every pass of
+ * the schedule under up to max_candidates orders of its bits (ascending first, then seeded permutations; budget_ms
+ * bounds the total, 0 = unbounded); the fastest order per (register size, precision, tile shape, bit set) is kept in
+ * a process-wide table that every later run with that geometry uses.  The state's contents are clobbered: it is left
+ * reset to |0...0>.  Not part of any timed region — call it once per circuit shape, like building a plan. */
+typedef struct {
+    int tile_passes;      /* tile passes in the circuit's schedule */
+    int already_known;    /* ... whose geometry was in the table already */
+    int passes_tuned;     /* ... measured now */
+    int passes_reordered; /* ... for which an order beat ascending by more than the timing noise */
+    int candidates_timed;
+    double ms_ascending;  /* sum over the measured passes: time in ascending order */
+    double ms_best;       /* ... and in the order kept */
+    double seconds;       /* wall time spent measuring */
+} qsim_tune_report;
+int qsim_tune_circuit(qsim_state *s, const qsim_circuit *circuit, int max_candidates, double budget_ms, qsim_tune_report *report);
+long qsim_tune_table_size(void);
+void qsim_tune_table_clear(void);
 
 /* ---- circuits: the tokenizer of compute_state_vector (quantum_simulator.c:115-254) ---------------- */
 /* Parses the OPENQASM-3 subset of quantum_simulator.c (two header statements, `qubit[n] q;` or

@@ -700,6 +700,52 @@ def test_edge_cases_empty_tiny_and_auto_flush(oracle, tmp_path):
         assert a[0] == 1 and not a[1:].any()
 
 
+@pytest.mark.parametrize("n,depth,seed,vocab,opts", [(16, 500, 31, "all", {}), (20, 700, 32, "all", {}), (14, 400, 33, "clifford_t", {}),
+                                                   (18, 600, 34, "all", {"tile_bits": 11, "tile_low_bits": 3}),
+                                                   (17, 500, 35, "all", {"tile_bits": 13, "tile_low_bits": 4})])
+def test_tile_bit_order_does_not_change_results(oracle, tmp_path, n, depth, seed, vocab, opts):
+    """The engine may walk a pass's high tile bits in any order (TileGeom::high need not ascend): every block form must
+    translate its qubits through the order it is given.  QSIM_OPT_DEBUG_TILE_ORDER shuffles every pass's order."""
+    gates = circuits.random_gates(n, depth, seed, vocab)
+    path = circuits.write_qasm(str(tmp_path / "c.qasm"), n, gates)
+    _, want, _, _ = oracle.run_qasm(path)
+    c = Circuit.from_file(path)
+    for k in (1, 2, 3):
+        with Simulator(n, fuse=3, debug_tile_order=k, profile=True, **opts) as sim:
+            sim.run(c)
+            got = sim.read()
+            orders = [o for o in sim.launch_log_orders() if o]
+        assert np.max(np.abs(got - want)) < TOL, k
+        assert any(o != sorted(o) for o in orders)  # the orders really were shuffled
+
+
+def test_geometry_planning_keeps_results_and_fills_the_table(oracle, tmp_path):
+    """qsim_tune_circuit: measures candidate orders for every pass of the schedule, leaves the state reset, and a later
+    run of the same circuit (which now uses the measured orders) still equals the oracle."""
+    lib = _lib.load()
+    n, depth = 20, 600
+    gates = circuits.random_gates(n, depth, 36, "all")
+    path = circuits.write_qasm(str(tmp_path / "c.qasm"), n, gates)
+    _, want, _, _ = oracle.run_qasm(path)
+    c = Circuit.from_file(path)
+    lib.qsim_tune_table_clear()
+    with Simulator(n, fuse=3, profile=True) as sim:
+        sim.apply_1q(gate_matrix("h"), 3)  # pending work is flushed first, then the state comes back reset
+        rep = sim.tune(c, max_candidates=6, budget_ms=0)
+        assert rep["tile_passes"] >= 2 and rep["passes_tuned"] >= 2 and rep["candidates_timed"] >= rep["passes_tuned"]
+        assert rep["ms_best"] <= rep["ms_ascending"] + 1e-9
+        assert lib.qsim_tune_table_size() == rep["passes_tuned"]
+        a = sim.read(0, 16)
+        assert a[0] == 1 and not a[1:].any()
+        sim.reset_stats()
+        sim.run(c)
+        assert np.max(np.abs(sim.read() - want)) < TOL
+        again = sim.tune(c, max_candidates=6, budget_ms=0)
+        assert again["passes_tuned"] == 0 and again["already_known"] == rep["passes_tuned"]
+    lib.qsim_tune_table_clear()
+    assert lib.qsim_tune_table_size() == 0
+
+
 def test_randomised_geometry_sweep(oracle, tmp_path):
     """Seeded sweep over register sizes, vocabularies and every engine option (tile size, low bits, ops per pass,
     threads, padding start, grid cap): each case against the oracle.  Catches geometry corner cases (n just above the

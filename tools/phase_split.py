@@ -28,6 +28,7 @@ with Simulator(n, fuse=3, profile=True, **opts) as sim:
     sim.set_option(_lib.OPT_DEBUG_SKIP_MEM, 0)
     t = [0.0, 0.0, 0.0]
     for (k, nops, hm, ms), (_, _, _, m0), (_, _, _, o0) in zip(full, mem, ops):
-        print(f"{k:6s} blocks={nops:2d} full={ms:7.3f} mem_only={m0:7.3f} ops_only={o0:7.3f}", flush=True)
+        bits = [b for b in range(40) if hm >> b & 1]
+        print(f"{k:6s} blocks={nops:2d} full={ms:7.3f} mem_only={m0:7.3f} ops_only={o0:7.3f} high={bits}", flush=True)
         t[0] += ms; t[1] += m0; t[2] += o0
     print(f"total full={t[0]:.2f} mem_only={t[1]:.2f} ops_only={t[2]:.2f}  passes={len(full)}", flush=True)

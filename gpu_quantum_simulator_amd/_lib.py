@@ -93,6 +93,7 @@ SIGNATURES = {
     "qsim_cluster_exchange_stats": (c_int, [c_void_p, POINTER(c_uint64), _DP]),
     "qsim_cluster_error": (c_char_p, []),
     "qsim_cluster_exchange_mode": (c_char_p, [c_void_p]),
+    "qsim_shard_plan_tune": (c_int, [c_void_p, c_int, c_void_p, c_int, c_double, POINTER(QsimTuneReport)]),
     "qsim_shard_plan_predict": (c_int, [c_void_p, c_double, c_double, _DP, _DP]),
     "qsim_rccl_unique_id": (c_int, [c_void_p]),
     "qsim_rank_comm_create": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -114,6 +115,8 @@ SIGNATURES = {
     "qsim_tune_circuit": (c_int, [c_void_p, c_void_p, c_int, c_double, POINTER(QsimTuneReport)]),
     "qsim_tune_table_size": (c_long, []),
     "qsim_tune_table_clear": (None, []),
+    "qsim_tune_table_save": (c_int, [c_char_p]),
+    "qsim_tune_table_load": (c_long, [c_char_p]),
     "qsim_circuit_parse_file": (c_int, [c_char_p, POINTER(c_void_p)]),
     "qsim_circuit_parse_text": (c_int, [c_char_p, c_size_t, POINTER(c_void_p)]),
     "qsim_circuit_create": (c_int, [c_int, POINTER(c_void_p)]),

@@ -939,3 +939,38 @@ extern "C" int qsim_rank_comm_loopback(qsim_rank_comm *c, uint64_t count) {
     if (memcmp(a.data(), b.data(), count * 8) != 0) return cfail(QSIM_ERR_DEVICE, "RCCL loopback: received data differs");
     return QSIM_OK;
 }
+
+// Geometry planning for a shard's part of a plan: every local step's ops for `shard` as a circuit through
+// qsim_tune_circuit (include/qsim.h, "measured pass geometry").  Leaves `s` reset; budget_ms bounds the total.
+extern "C" int qsim_shard_plan_tune(const qsim_shard_plan *p, int shard, qsim_state *s, int max_candidates, double budget_ms,
+                                    qsim_tune_report *report) {
+    if (!p || !s || shard < 0 || shard >= p->P) return cfail(QSIM_ERR_ARG, "bad argument");
+    qsim_tune_report total{};
+    int locals = 0;
+    for (const Step &st : p->plan.steps) locals += !st.exchange;
+    for (const Step &st : p->plan.steps) {
+        if (st.exchange) continue;
+        qsim_circuit *c = nullptr;
+        int rc = qsim_circuit_create(p->plan.m, &c);
+        for (const LocalOp &o : st.per_shard[(size_t)shard]) {
+            if (rc) break;
+            if (o.kind == 2) rc = qsim_circuit_append_cx(c, o.a, o.b);
+            else {
+                const cd z = o.m[0];
+                const double U[8] = {o.m[0].real(), o.m[0].imag(), o.kind == 1 ? o.m[1].real() : 0.0, o.kind == 1 ? o.m[1].imag() : 0.0,
+                                     o.kind == 1 ? o.m[2].real() : 0.0, o.kind == 1 ? o.m[2].imag() : 0.0,
+                                     o.kind == 1 ? o.m[3].real() : z.real(), o.kind == 1 ? o.m[3].imag() : z.imag()};
+                rc = qsim_circuit_append_1q(c, U, o.kind == 1 ? o.a : 0); // kind 3: the scalar as diag(z, z) on local qubit 0 (qsim_scale)
+            }
+        }
+        qsim_tune_report r{};
+        if (rc == QSIM_OK) rc = qsim_tune_circuit(s, c, max_candidates, budget_ms > 0 ? budget_ms / locals : 0.0, &r);
+        qsim_circuit_free(c);
+        if (rc) return cfail(rc, "%s", qsim_last_error());
+        total.tile_passes += r.tile_passes; total.already_known += r.already_known; total.passes_tuned += r.passes_tuned;
+        total.passes_reordered += r.passes_reordered; total.candidates_timed += r.candidates_timed;
+        total.ms_ascending += r.ms_ascending; total.ms_best += r.ms_best; total.seconds += r.seconds;
+    }
+    if (report) *report = total;
+    return QSIM_OK;
+}

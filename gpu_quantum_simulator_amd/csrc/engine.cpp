@@ -1079,6 +1079,56 @@ extern "C" long qsim_tune_table_size(void) {
     return (long)g_wisdom.size();
 }
 
+// The table as text, one geometry per line: n f32 tile_bits low_bits high_mask(hex) ms ms_ascending order...  A table
+// measured once (per machine) can be loaded by later processes: the C host does so when QSIM_WISDOM names a file.
+extern "C" int qsim_tune_table_save(const char *path) {
+    if (!path) return fail(QSIM_ERR_ARG, "NULL path");
+    FILE *f = fopen(path, "w");
+    if (!f) return fail(QSIM_ERR_OPEN, "cannot write %s", path);
+    std::lock_guard<std::mutex> lock(g_wisdom_mu);
+    for (const auto &kv : g_wisdom) {
+        const int nh = __builtin_popcountll(kv.first.high_mask);
+        fprintf(f, "%d %d %d %d %llx %.4f %.4f", kv.first.n, kv.first.f32, kv.first.tile_bits, kv.first.low_bits,
+                (unsigned long long)kv.first.high_mask, kv.second.ms, kv.second.ms_ascending);
+        for (int j = 0; j < nh; j++) fprintf(f, " %d", (int)kv.second.high[j]);
+        fprintf(f, "\n");
+    }
+    fclose(f);
+    return QSIM_OK;
+}
+
+extern "C" long qsim_tune_table_load(const char *path) {
+    if (!path) return -1;
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    long loaded = 0;
+    char line[512];
+    while (fgets(line, sizeof line, f)) {
+        GeomKey k{};
+        GeomOrder o{};
+        unsigned long long hm = 0;
+        int used = 0;
+        if (sscanf(line, "%d %d %d %d %llx %f %f%n", &k.n, &k.f32, &k.tile_bits, &k.low_bits, &hm, &o.ms, &o.ms_ascending, &used) < 7) continue;
+        k.high_mask = hm;
+        const int nh = __builtin_popcountll(hm);
+        if (nh < 2 || nh > kMaxTileHigh) continue;
+        const char *p = line + used;
+        uint64_t seen = 0;
+        bool ok = true;
+        for (int j = 0; j < nh && ok; j++) {
+            int v = -1, adv = 0;
+            if (sscanf(p, "%d%n", &v, &adv) < 1 || v < 0 || v > 62 || !((hm >> v) & 1ULL) || ((seen >> v) & 1ULL)) ok = false;
+            else { o.high[j] = (int8_t)v; seen |= 1ULL << v; p += adv; }
+        }
+        if (!ok) continue; // not a permutation of the set: ignore the line
+        std::lock_guard<std::mutex> lock(g_wisdom_mu);
+        g_wisdom[k] = o;
+        loaded++;
+    }
+    fclose(f);
+    return loaded;
+}
+
 extern "C" void qsim_tune_table_clear(void) {
     std::lock_guard<std::mutex> lock(g_wisdom_mu);
     g_wisdom.clear();

@@ -91,6 +91,10 @@ class ShardPlan:
         2^-k of the shard over each of 2^k - 1 links at once."""
         return self.handle.predict(link_gbps, pack_gbps)
 
+    def tune(self, sim, max_candidates: int = 32, budget_ms: float = 6000.0) -> dict:
+        """Geometry planning for this rank's local steps (qsim_shard_plan_tune); leaves `sim` reset."""
+        return self.handle.tune(self.rank, sim, max_candidates, budget_ms)
+
     def apply_local(self, step: int, sim) -> None:
         """Queues this rank's ops of a local step on a Simulator, natively."""
         self.handle.apply_local(step, self.rank, sim)
@@ -284,6 +288,12 @@ class ShardedSimulator:
         if dev.type == "cuda":
             torch.cuda.synchronize()
         dist.barrier()
+
+    def tune(self, max_candidates: int = 32, budget_ms: float = 6000.0):
+        """Plans the pass geometries of this rank's local steps (HIP shards only; a no-op for test backends)."""
+        if hasattr(self.shard, "sim"):
+            return self.plan.tune(self.shard.sim, max_candidates, budget_ms)
+        return None
 
     def run_step(self):
         import time

@@ -435,6 +435,14 @@ class ShardPlanHandle:
         check(_lib.load().qsim_shard_plan_final_pos(self._h, pos))
         return list(pos)
 
+    def tune(self, shard: int, sim: "Simulator", max_candidates: int = 32, budget_ms: float = 6000.0) -> dict:
+        """qsim_shard_plan_tune: geometry planning for one shard's local steps (leaves `sim` reset)."""
+        rep = _lib.QsimTuneReport()
+        rc = _lib.load().qsim_shard_plan_tune(self._h, shard, sim._h, max_candidates, budget_ms, byref(rep))
+        if rc:
+            raise _lib.QsimError(rc, (_lib.load().qsim_cluster_error() or b"").decode())
+        return rep.as_dict()
+
     def predict(self, link_gbps: float = 50.0, pack_gbps: float = 5000.0):
         """(bytes each rank sends, seconds spent in exchanges) under the planner's cost model (qsim_shard_plan_predict)."""
         b, t = c_double(), c_double()

@@ -151,6 +151,30 @@ double qsim_draw_randn(void);
 /* putb (:285-293): `len` binary digits of n, most significant first, NUL-terminated into buf (len + 1 bytes). */
 void qsim_putb(long long n, int len, char *buf);
 
+/* ---- measured pass geometry (planning, in the sense of FFTW's wisdom) -------------------------------------------------
+ * A cache-blocked pass walks nine "high" index bits besides the contiguous low ones; which of them the lanes of a wave,
+ * the waves of a workgroup and the registers of a lane walk changes nothing in the result and up to 2x in the pass's
+ * HBM time (DESIGN.md section 4).  qsim_tune_circuit plans `circuit` as qsim_run_circuit would and times every pass of
+ * the schedule under up to max_candidates orders of its bits (ascending first, then seeded permutations; budget_ms
+ * bounds the total, 0 = unbounded); the fastest order per (register size, precision, tile shape, bit set) is kept in
+ * a process-wide table that every later run with that geometry uses.  The state's contents are clobbered: it is left
+ * reset to |0...0>.  Not part of any timed region — call it once per circuit shape, like building a plan. */
+typedef struct {
+    int tile_passes;      /* tile passes in the circuit's schedule */
+    int already_known;    /* ... whose geometry was in the table already */
+    int passes_tuned;     /* ... measured now */
+    int passes_reordered; /* ... for which an order beat ascending by more than the timing noise */
+    int candidates_timed;
+    double ms_ascending;  /* sum over the measured passes: time in ascending order */
+    double ms_best;       /* ... and in the order kept */
+    double seconds;       /* wall time spent measuring */
+} qsim_tune_report;
+int qsim_tune_circuit(qsim_state *s, const qsim_circuit *circuit, int max_candidates, double budget_ms, qsim_tune_report *report);
+long qsim_tune_table_size(void);
+void qsim_tune_table_clear(void);
+int qsim_tune_table_save(const char *path);  /* text, one geometry per line */
+long qsim_tune_table_load(const char *path); /* entries loaded (malformed lines are skipped), -1 if the file cannot be read */
+
 /* ---- sharded states (new: the reference is single-device) --------------------------------
  * A qsim_state may hold one contiguous shard of a larger register: the caller (one process per GPU)
  * keeps the top log2(P) index bits as the rank id and owns the logical->physical qubit map.
@@ -224,6 +248,8 @@ int qsim_shard_plan_apply_local(const qsim_shard_plan *p, int step, int shard, q
  * sum over exchanges of (pack pass: 2 * shard bytes / pack_gbps) + (largest per-link transfer: 2^-k of the shard /
  * link_gbps; a k-qubit swap uses 2^k - 1 links in both directions at once).  The planner itself keeps the cheaper of
  * two placements (keep far-next-use globals vs swap all log2 P of them) under the same model with default rates. */
+/* Geometry planning (qsim_tune_circuit) for one shard's local steps of the plan; leaves the shard state reset. */
+int qsim_shard_plan_tune(const qsim_shard_plan *p, int shard, qsim_state *s, int max_candidates, double budget_ms, qsim_tune_report *report);
 int qsim_shard_plan_predict(const qsim_shard_plan *p, double link_gbps, double pack_gbps, double *bytes_per_rank, double *seconds);
 
 /* ---- one process per GPU: the exchanges on RCCL (pairwise ncclSend/ncclRecv of half-shards for one global
@@ -253,28 +279,6 @@ long qsim_launch_log(qsim_state *s, long index, int *kernel_class, int *n_ops, u
  * the first three are walked by the lanes of a wave, the next by its waves, the last by a lane's registers); count = 0
  * for other kernels.  order needs room for 10 entries. */
 int qsim_launch_log_order(qsim_state *s, long index, int *order, int *count);
-
-/* ---- measured pass geometry (planning, in the sense of FFTW's wisdom) -------------------------------------------------
- * A cache-blocked pass walks nine "high" index bits besides the contiguous low ones; which of them the lanes of a wave,
- * the waves of a workgroup and the registers of a lane walk changes nothing in the result and up to 2x in the pass's
- * HBM time (DESIGN.md section 4).  qsim_tune_circuit plans `circuit` as qsim_run_circuit would and times every pass of
- * the schedule under up to max_candidates orders of its bits (ascending first, then seeded permutations; budget_ms
- * bounds the total, 0 = unbounded); the fastest order per (register size, precision, tile shape, bit set) is kept in
- * a process-wide table that every later run with that geometry uses.  The state's contents are clobbered: it is left
- * reset to |0...0>.  Not part of any timed region — call it once per circuit shape, like building a plan. */
-typedef struct {
-    int tile_passes;      /* tile passes in the circuit's schedule */
-    int already_known;    /* ... whose geometry was in the table already */
-    int passes_tuned;     /* ... measured now */
-    int passes_reordered; /* ... for which an order beat ascending by more than the timing noise */
-    int candidates_timed;
-    double ms_ascending;  /* sum over the measured passes: time in ascending order */
-    double ms_best;       /* ... and in the order kept */
-    double seconds;       /* wall time spent measuring */
-} qsim_tune_report;
-int qsim_tune_circuit(qsim_state *s, const qsim_circuit *circuit, int max_candidates, double budget_ms, qsim_tune_report *report);
-long qsim_tune_table_size(void);
-void qsim_tune_table_clear(void);
 
 /* ---- circuits: the tokenizer of compute_state_vector (quantum_simulator.c:115-254) ---------------- */
 /* Parses the OPENQASM-3 subset of quantum_simulator.c (two header statements, `qubit[n] q;` or

@@ -33,6 +33,25 @@ def test_header_and_binding_agree():
         assert re.search(rf"\b{name}\s*\(", legacy)
 
 
+def test_geometry_table_file_round_trip(tmp_path):
+    """qsim_tune_table_save / _load (the table qsim_tune_circuit fills on a GPU): text lines, malformed ones skipped."""
+    lib = _lib.load()
+    lib.qsim_tune_table_clear()
+    src = tmp_path / "wisdom.txt"
+    src.write_text("30 0 12 3 3b00000 6.5600 7.6700 25 20 24 21 23\n"          # five bits: 20, 21, 23, 24, 25
+                   "28 1 13 4 30300 1.9000 2.1000 8 17 9 16\n"
+                   "30 0 12 3 3b00000 6.5 7.6 25 20 24 21 22\n"                  # 22 is not in the set: skipped
+                   "garbage\n")
+    assert lib.qsim_tune_table_load(str(src).encode()) == 2 and lib.qsim_tune_table_size() == 2
+    out = tmp_path / "out.txt"
+    assert lib.qsim_tune_table_save(str(out).encode()) == 0
+    lines = sorted(out.read_text().splitlines())
+    assert lines == ["28 1 13 4 30300 1.9000 2.1000 8 17 9 16", "30 0 12 3 3b00000 6.5600 7.6700 25 20 24 21 23"]
+    assert lib.qsim_tune_table_load(str(tmp_path / "missing.txt").encode()) == -1
+    lib.qsim_tune_table_clear()
+    assert lib.qsim_tune_table_size() == 0
+
+
 def test_no_device_means_loud_failure_not_fallback():
     lib = _lib.load()
     if lib.qsim_device_count() > 0:

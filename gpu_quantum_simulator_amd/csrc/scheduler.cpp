@@ -328,6 +328,40 @@ bool TileBlock::classes(int &T, std::vector<std::vector<int>> &rows, std::vector
     return true;
 }
 
+bool TileBlock::classes_feasible() const {
+    const int D = dim(), NB = banks();
+    if (D > 32) return false;
+    int maxsz = 1;
+    int cnt[kMaxBanks][kMaxRowNnz + 1]; // components by size, per bank
+    for (int v = 0; v < NB; v++) {
+        unsigned char parent[64], nrow[64], ncol[64];
+        for (int i = 0; i < 2 * D; i++) { parent[i] = (unsigned char)i; nrow[i] = ncol[i] = 0; }
+        auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+        for (int r = 0; r < D; r++)
+            for (int j = 0; j < row(v, r).n; j++) {
+                const int a = find(r), b = find(D + row(v, r).col[j]);
+                if (a != b) parent[a] = (unsigned char)b;
+            }
+        for (int r = 0; r < D; r++) nrow[find(r)]++;
+        for (int c = 0; c < D; c++) ncol[find(D + c)]++;
+        for (int s = 0; s <= kMaxRowNnz; s++) cnt[v][s] = 0;
+        for (int i = 0; i < 2 * D; i++) {
+            if (parent[i] != i || (nrow[i] == 0 && ncol[i] == 0)) continue;
+            if (nrow[i] != ncol[i] || nrow[i] > kMaxRowNnz) return false;
+            cnt[v][nrow[i]]++;
+            maxsz = std::max(maxsz, (int)nrow[i]);
+        }
+    }
+    const int T = maxsz <= 1 ? 1 : maxsz <= 2 ? 2 : 4;
+    if (D % T) return false;
+    if (T < 4) return true; // sizes 1 and 2 always fill bins of 2 (D is even)
+    for (int v = 0; v < NB; v++) { // bins of 4: every 3 takes a 1, an odd 2 takes two 1s, the rest fills up by itself
+        const int ones = cnt[v][1] - cnt[v][3];
+        if (ones < 0 || ones < 2 * (cnt[v][2] & 1)) return false;
+    }
+    return true;
+}
+
 // Splits a fused op (1 or 2 qubits at level 3) by the tile: qubits in `inside` stay matrix indices, the others become
 // bank selectors.  The op must be block-diagonal in every qubit left outside.
 static TileBlock to_block(const FusedOp &op, uint64_t inside) {
@@ -750,11 +784,7 @@ void Scheduler::merge_blocks(std::vector<TileBlock> &blocks) const {
                         }
                     }
                 }
-                if (fits && k >= 2) { // one LDS trip evaluates whole row classes (TileBlock::classes): the product must have them
-                    int T;
-                    std::vector<std::vector<int>> cr, cc;
-                    fits = m.classes(T, cr, cc);
-                }
+                if (fits && k >= 2) fits = m.classes_feasible(); // one LDS trip evaluates whole row classes (TileBlock::classes)
                 if (fits) {
                     for (int v = 0; v < (1 << nss); v++) // keep every row's entries in ascending column order
                         for (int r = 0; r < D; r++) {

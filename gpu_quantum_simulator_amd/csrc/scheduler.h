@@ -91,6 +91,7 @@ struct TileBlock {
     // can be skipped.  false: some component is larger than kMaxRowNnz or the packing leaves a gap (such a block is
     // never built: merge_blocks asks first).
     bool classes(int &T, std::vector<std::vector<int>> &rows, std::vector<std::vector<int>> &cols) const;
+    bool classes_feasible() const; // the same answer as classes() without building the layout (no heap: merge_blocks asks often)
 };
 
 struct Pass {

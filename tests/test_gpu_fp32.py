@@ -140,6 +140,7 @@ def test_sampling_and_pack_fp32():
             wide.write(s32.astype(np.complex128))
             assert np.array_equal(idx, wide.sample(r))
         dst = torch.zeros((1 << n, 2), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()  # the fill runs on torch's stream, the pack on the engine's: order them
         sim.pack_bits((3, 11), dst.data_ptr())
         sim.sync()
         got = dst.cpu().numpy().reshape(-1).view(np.complex64)

@@ -386,6 +386,7 @@ def test_pack_bits_layout(bits):
     with Simulator(n) as sim:
         sim.write(s)
         dst = torch.zeros((1 << n, 2), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()  # the fill runs on torch's stream, the pack on the engine's: order them
         sim.pack_bits(bits, dst.data_ptr())
         sim.sync()
         got = dst.cpu().numpy().reshape(-1).view(np.complex128)
@@ -413,8 +414,9 @@ def test_pack_bits_to_separate_blocks_and_buffer_swap(bits):
     with Simulator(n) as sim:
         sim.write(s)
         ref = torch.zeros((1 << n, 2), dtype=torch.float64, device="cuda")
-        sim.pack_bits(bits, ref.data_ptr())
         big = torch.zeros((2 << n, 2), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()  # the fills run on torch's stream, the packs on the engine's: order them
+        sim.pack_bits(bits, ref.data_ptr())
         starts = [(2 * ((1 << k) - 1 - b)) * blk for b in range(1 << k)]  # reverse order, a gap after every block
         sim.pack_bits_to(bits, [big.data_ptr() + 16 * st for st in starts])
         sim.sync()
@@ -429,6 +431,7 @@ def test_pack_bits_to_separate_blocks_and_buffer_swap(bits):
     with Simulator(n) as sim:
         sim.write(s)
         spare_t = torch.zeros((1 << n, 2), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
         spare = spare_t.data_ptr()
         old_ptr = sim.device_ptr
         sim.pack_bits_to(bits[:1], [spare, spare + 16 * (1 << (n - 1))])  # spare = the state packed on bits[0]

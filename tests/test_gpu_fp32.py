@@ -95,6 +95,16 @@ def test_random_circuits_fp32(oracle, tmp_path, n, depth, seed, vocab, opts):
     assert np.max(np.abs(got - want)) < TOL32
 
 
+@pytest.mark.parametrize("order_seed", [1, 2])
+def test_tile_bit_order_fp32(oracle, tmp_path, order_seed):
+    """Shuffled tile-bit orders (QSIM_OPT_DEBUG_TILE_ORDER) through the fp32 instantiation of the tile kernel."""
+    n = 17
+    path = circuits.random_circuit_file(str(tmp_path / "c.qasm"), n, 500, 91, "all")
+    _, want, _, _ = oracle.run_qasm(path)
+    got = run_qasm(path, fuse=3, precision=32, debug_tile_order=order_seed)
+    assert np.max(np.abs(got - want)) < TOL32
+
+
 def test_randomised_geometry_sweep_fp32(oracle, tmp_path):
     rng = np.random.default_rng(77)
     for case in range(30):

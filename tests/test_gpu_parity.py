@@ -637,9 +637,11 @@ def test_measurement_post_path(oracle, golden_dir, tmp_path):
     assert all(l in ("MEASUREMENT: 00 (0)", "MEASUREMENT: 11 (3)") for l in lines[1:])
 
 
-@pytest.mark.parametrize("shards", [2, 4, 8])
+@pytest.mark.parametrize("shards", [2, 4, 8, 16])
 def test_c_host_cluster_virtual_shards(oracle, tmp_path, shards):
-    """qsim_cluster (csrc/dist.cpp): the C host's one-process sharded path, all shards on device 0."""
+    """qsim_cluster (csrc/dist.cpp): the C host's one-process sharded path, all shards on device 0.  Sixteen shards swap
+    up to four qubits at once, more than the one-kernel exchange takes (eight block destinations): those exchanges go
+    through the pack + copy form, in the same run as one-kernel ones."""
     from gpu_quantum_simulator_amd import Cluster
     n = 17
     path = circuits.random_circuit_file(str(tmp_path / "c.qasm"), n, 600, 80 + shards, "all")

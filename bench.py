@@ -400,6 +400,8 @@ def main():
                        "launches_per_step": r["stats"]["launches"] / r["steps"], "norm2": r["norm2"],
                        "geometry_planning": r["tuning"],
                        "roofline": None if rf is None else {k: rf[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms")}}
+                if (16 << r["n"]) <= (256 << 20) and row["roofline"]:
+                    row["roofline"]["note"] = "the state fits the 256 MiB Infinity Cache: passes run from cache, the HBM roofline does not bound them"
                 if "exchange" in r:
                     row["exchange"] = r["exchange"]
                 if cpu:

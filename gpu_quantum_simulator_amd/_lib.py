@@ -17,6 +17,7 @@ OPT_TILE_PAD_FROM = 9
 OPT_DEBUG_SKIP_OPS = 10
 OPT_DEBUG_SKIP_MEM = 11
 OPT_DEBUG_TILE_ORDER = 12
+OPT_PLAN_CACHE = 13
 K_NAMES = ("init", "gate1", "gate1_lo", "phase", "cx", "gate2", "tile", "pack")
 K_COUNT = len(K_NAMES)
 

@@ -5,6 +5,7 @@
 // usable device, qsim_create() fails with QSIM_ERR_DEVICE.
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -75,6 +76,14 @@ struct ProfEvent {
 };
 struct LaunchRec { int kclass, n_ops; uint64_t high_mask; double ms; uint64_t order_code; };
 
+struct CachedPlan {
+    uint64_t key = 0, wisdom_epoch = 0, last_use = 0;
+    std::vector<Pass> passes;
+    std::vector<TileGeom> geoms;   // per pass; meaningful for tile passes: the geometry in the order it was launched with
+    std::vector<size_t> op_first;  // per pass: index of its first TileOp in d_ops
+    TileOp *d_ops = nullptr;
+};
+
 struct qsim_state {
     int n = 0, device = 0;
     hipStream_t stream = nullptr;
@@ -99,6 +108,13 @@ struct qsim_state {
     std::vector<ProfEvent> events;      // recorded, not yet resolved
     std::vector<LaunchRec> launch_log;  // per-launch times since the last qsim_reset_stats (profile mode)
     std::vector<hipEvent_t> event_pool; // reusable
+    // Plans of recently flushed gate queues (QSIM_OPT_PLAN_CACHE): the passes as scheduled, the tile passes' bit orders and
+    // their TileOps resident on the device.  A queue that hashes to a cached plan is replayed launch by launch — no
+    // scheduling, no block preparation, no H2D copy — which is what a loop that re-runs one circuit shape (a benchmark's
+    // steps, a variational algorithm's iterations) pays for at n <= 26, where a pass is shorter than its planning.
+    std::vector<struct CachedPlan> plans;
+    uint64_t plan_clock = 0;
+    int plan_cache = 1;
 };
 
 static constexpr size_t kOpsCap = 512;  // a pass holds <= tile_max_ops blocks; the ring wraps with a stream sync
@@ -151,6 +167,8 @@ extern "C" void qsim_destroy(qsim_state *s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (auto &pe : s->events) { (void)hipEventDestroy(pe.start); (void)hipEventDestroy(pe.stop); }
     for (auto ev : s->event_pool) (void)hipEventDestroy(ev);
+    for (CachedPlan &pl : s->plans)
+        if (pl.d_ops) (void)hipFree(pl.d_ops);
     if (s->owns && s->amps) (void)hipFree(s->amps);
     if (s->d_ops) (void)hipFree(s->d_ops);
     if (s->h_ops) (void)hipHostFree(s->h_ops);
@@ -214,6 +232,9 @@ extern "C" int qsim_set_option(qsim_state *s, int option, long value) {
     case QSIM_OPT_DEBUG_TILE_ORDER:
         s->debug_tile_order = (int)value;
         break;
+    case QSIM_OPT_PLAN_CACHE:
+        s->plan_cache = value != 0;
+        break;
 
     case QSIM_OPT_TILE_THREADS:
         if (value != 0 && value != 256 && value != 512 && value != 1024)
@@ -240,6 +261,7 @@ extern "C" long qsim_get_option(const qsim_state *s, int option) {
     case QSIM_OPT_DEBUG_SKIP_OPS: return s->debug_skip_ops;
     case QSIM_OPT_DEBUG_SKIP_MEM: return s->debug_skip_mem;
     case QSIM_OPT_DEBUG_TILE_ORDER: return s->debug_tile_order;
+    case QSIM_OPT_PLAN_CACHE: return s->plan_cache;
     default: return -1;
     }
 }
@@ -513,6 +535,7 @@ struct GeomKey {
 struct GeomOrder { int8_t high[kMaxTileHigh]; float ms, ms_ascending; };
 static std::mutex g_wisdom_mu;
 static std::map<GeomKey, GeomOrder> g_wisdom;
+static std::atomic<uint64_t> g_wisdom_epoch{1}; // bumped whenever the table changes: cached plans carry the orders they were built with
 
 static GeomKey geom_key(const qsim_state *s, const TileGeom &g) {
     GeomKey k{g.n, s->f32 ? 1 : 0, g.tile_bits, g.low_bits, 0};
@@ -542,8 +565,25 @@ static void order_tile_bits(qsim_state *s, TileGeom &g) {
         for (int j = 0; j < g.n_high; j++) g.high[j] = it->second.high[j];
 }
 
-// Uploads the blocks of a tile pass for the given bit order and launches it (no statistics, no profiling events).
-static int launch_tile_pass(qsim_state *s, const Pass &p, const TileGeom &geom, bool from_zero_ket) {
+// Launches a tile pass whose TileOps are already on the device (no statistics, no profiling events).
+static int launch_tile_prepared(qsim_state *s, const TileGeom &geom, const TileOp *d, int need, bool from_zero_ket) {
+    LaunchCfg cfg{s->stream, s->grid_cap};
+    const int threads = s->tile_threads; // 0: default for the tile size
+    hipError_t e;
+    if (s->debug_skip_ops) {
+        TileGeom bare = geom;
+        bare.n_scale = 0;
+        e = launch_tile(cfg, s->amps, s->f32, bare, d, 0, threads, from_zero_ket, s->zero_ket_amp);
+    } else {
+        e = launch_tile(cfg, s->amps, s->f32, geom, d, need, threads, from_zero_ket, s->zero_ket_amp, s->debug_skip_mem != 0);
+    }
+    if (e != hipSuccess) return fail(QSIM_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+    return QSIM_OK;
+}
+
+// Prepares the blocks of a tile pass for the given bit order in the pinned ring, uploads and launches them; `capture`
+// (optional) receives a copy of the prepared TileOps for the plan cache.
+static int launch_tile_pass(qsim_state *s, const Pass &p, const TileGeom &geom, bool from_zero_ket, std::vector<TileOp> *capture = nullptr) {
     const size_t need = p.blocks.size();
     if (need > s->ops_cap) return fail(QSIM_ERR_ARG, "tile pass with %zu ops exceeds the op buffer", need);
     if (s->ops_used + need > s->ops_cap) { // ring is full: wait until earlier passes have read their ops
@@ -561,24 +601,17 @@ static int launch_tile_pass(qsim_state *s, const Pass &p, const TileGeom &geom, 
                 memcpy(h[k].re[v], fr, sizeof fr);
                 memcpy(h[k].im[v], fi, sizeof fi);
             }
+    if (capture) capture->insert(capture->end(), h, h + need);
     TileOp *d = s->d_ops + s->ops_used;
     HIP_TRY(hipMemcpyAsync(d, h, need * sizeof(TileOp), hipMemcpyHostToDevice, s->stream));
     s->ops_used += need;
-    LaunchCfg cfg{s->stream, s->grid_cap};
-    const int threads = s->tile_threads; // 0: default for the tile size
-    hipError_t e;
-    if (s->debug_skip_ops) {
-        TileGeom bare = geom;
-        bare.n_scale = 0;
-        e = launch_tile(cfg, s->amps, s->f32, bare, d, 0, threads, from_zero_ket, s->zero_ket_amp);
-    } else {
-        e = launch_tile(cfg, s->amps, s->f32, geom, d, (int)need, threads, from_zero_ket, s->zero_ket_amp, s->debug_skip_mem != 0);
-    }
-    if (e != hipSuccess) return fail(QSIM_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
-    return QSIM_OK;
+    return launch_tile_prepared(s, geom, d, (int)need, from_zero_ket);
 }
 
-static int launch_pass(qsim_state *s, const Pass &p) {
+// cached_geom / cached_ops: replay of a cached plan (the tile pass's order and device-resident TileOps);
+// capture / geom_out: the first run of a plan records them.
+static int launch_pass(qsim_state *s, const Pass &p, const TileGeom *cached_geom = nullptr, const TileOp *cached_ops = nullptr,
+                       std::vector<TileOp> *capture = nullptr, TileGeom *geom_out = nullptr) {
     const bool from_zero_ket = s->zero_ket_pending && p.kclass == QSIM_K_TILE;
     if (s->zero_ket_pending && !from_zero_ket) {
         const int rc = materialize_zero_ket(s);
@@ -619,12 +652,14 @@ static int launch_pass(qsim_state *s, const Pass &p) {
         break;
     }
     case QSIM_K_TILE: {
-        TileGeom geom = p.geom;
-        order_tile_bits(s, geom);
+        TileGeom geom = cached_geom ? *cached_geom : p.geom;
+        if (!cached_geom) order_tile_bits(s, geom);
+        if (geom_out) *geom_out = geom;
         uint64_t hm = 0, oc = 0;
         for (int j = 0; j < geom.n_high; j++) { hm |= 1ULL << geom.high[j]; oc |= (uint64_t)geom.high[j] << (5 * j); }
         LaunchScope scope(s, p.kclass, (int)p.blocks.size(), hm, oc);
-        const int rc = launch_tile_pass(s, p, geom, from_zero_ket);
+        const int rc = cached_ops ? launch_tile_prepared(s, geom, cached_ops, (int)p.blocks.size(), from_zero_ket)
+                                  : launch_tile_pass(s, p, geom, from_zero_ket, capture);
         if (rc) return rc;
         break;
     }
@@ -636,12 +671,45 @@ static int launch_pass(qsim_state *s, const Pass &p) {
     return QSIM_OK;
 }
 
+static uint64_t queue_key(const qsim_state *s) {
+    uint64_t h = 0xcbf29ce484222325ULL; // FNV-1a over the options that shape a plan and over every queued gate
+    auto mix = [&](const void *p, size_t n) {
+        const unsigned char *b = (const unsigned char *)p;
+        for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ULL; }
+    };
+    const int opts[8] = {s->n, s->f32 ? 1 : 0, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, (int)s->queue.size()};
+    mix(opts, sizeof opts);
+    for (const QueuedGate &g : s->queue) {
+        const int hd[3] = {g.kind, g.q0, g.q1};
+        mix(hd, sizeof hd);
+        if (g.kind != QSIM_GATE_CX) mix(g.m, (g.kind == QSIM_GATE_U1 ? 4 : 16) * sizeof(cd));
+    }
+    return h;
+}
+
 extern "C" int qsim_flush(qsim_state *s) {
     if (!s) return fail(QSIM_ERR_ARG, "NULL state");
     if (s->queue.empty()) return QSIM_OK;
     if (s->tile_bits - s->tile_low_bits < 2 || s->tile_bits - s->tile_low_bits > kMaxTileHigh)
         return fail(QSIM_ERR_ARG, "tile_bits - tile_low_bits must be in 2..%d", kMaxTileHigh);
     HIP_TRY(hipSetDevice(s->device));
+    constexpr size_t kMaxPlans = 8, kMaxCachedOps = 4096;
+    const bool cacheable = s->plan_cache && s->fuse >= 3 && s->debug_tile_order == 0 && s->queue.size() >= 8;
+    const uint64_t key = cacheable ? queue_key(s) : 0;
+    const uint64_t epoch = g_wisdom_epoch.load();
+    if (cacheable) {
+        for (CachedPlan &pl : s->plans) {
+            if (pl.key != key || pl.wisdom_epoch != epoch) continue;
+            pl.last_use = ++s->plan_clock;
+            s->queue.clear();
+            for (size_t i = 0; i < pl.passes.size(); i++) {
+                const Pass &p = pl.passes[i];
+                const int rc = p.kclass == QSIM_K_TILE ? launch_pass(s, p, &pl.geoms[i], pl.d_ops + pl.op_first[i]) : launch_pass(s, p);
+                if (rc) return rc;
+            }
+            return QSIM_OK;
+        }
+    }
     Scheduler sched(sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32));
     for (const QueuedGate &g : s->queue) {
         if (g.kind == QSIM_GATE_U1) sched.add_1q(g.m, g.q0);
@@ -650,10 +718,48 @@ extern "C" int qsim_flush(qsim_state *s) {
     }
     s->queue.clear();
     int rc = QSIM_OK;
+    CachedPlan fresh;
+    std::vector<TileOp> host_ops;
     sched.finish([&](Pass &&p) { // launched as soon as it is scheduled: the GPU works while later passes are planned
-        if (rc == QSIM_OK) rc = launch_pass(s, p);
+        if (rc != QSIM_OK) return;
+        if (!cacheable) { rc = launch_pass(s, p); return; }
+        TileGeom g = p.geom;
+        fresh.op_first.push_back(host_ops.size());
+        rc = launch_pass(s, p, nullptr, nullptr, &host_ops, &g);
+        fresh.geoms.push_back(g);
+        fresh.passes.push_back(std::move(p));
     });
-    return rc;
+    if (rc != QSIM_OK || !cacheable || host_ops.size() > kMaxCachedOps) return rc;
+    // keep the plan: its TileOps move to a device buffer of their own (one copy, ordered behind the launches above)
+    if (!host_ops.empty()) {
+        if (hipMalloc((void **)&fresh.d_ops, host_ops.size() * sizeof(TileOp)) != hipSuccess) { (void)hipGetLastError(); return QSIM_OK; }
+        if (hipMemcpy(fresh.d_ops, host_ops.data(), host_ops.size() * sizeof(TileOp), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(fresh.d_ops);
+            (void)hipGetLastError();
+            return QSIM_OK;
+        }
+    }
+    fresh.key = key;
+    fresh.wisdom_epoch = epoch;
+    fresh.last_use = ++s->plan_clock;
+    size_t slot = s->plans.size();
+    for (size_t i = 0; i < s->plans.size(); i++) // a stale plan of the same queue (the geometry table changed) is replaced
+        if (s->plans[i].key == key) slot = i;
+    if (slot == s->plans.size() && s->plans.size() >= kMaxPlans) {
+        slot = 0;
+        for (size_t i = 1; i < s->plans.size(); i++)
+            if (s->plans[i].last_use < s->plans[slot].last_use) slot = i;
+    }
+    if (slot < s->plans.size()) {
+        if (s->plans[slot].d_ops) {
+            HIP_TRY(hipStreamSynchronize(s->stream)); // a replay of the evicted plan may still be reading its ops
+            (void)hipFree(s->plans[slot].d_ops);
+        }
+        s->plans[slot] = std::move(fresh);
+    } else {
+        s->plans.push_back(std::move(fresh));
+    }
+    return QSIM_OK;
 }
 
 extern "C" int qsim_sync(qsim_state *s) {
@@ -1063,6 +1169,7 @@ extern "C" int qsim_tune_circuit(qsim_state *s, const qsim_circuit *c, int max_c
         r.passes_tuned++;
         std::lock_guard<std::mutex> lock(g_wisdom_mu);
         g_wisdom[key] = best;
+        g_wisdom_epoch++;
     }
     s->debug_skip_mem = saved_skip_mem;
     (void)hipStreamSynchronize(s->stream);
@@ -1123,6 +1230,7 @@ extern "C" long qsim_tune_table_load(const char *path) {
         if (!ok) continue; // not a permutation of the set: ignore the line
         std::lock_guard<std::mutex> lock(g_wisdom_mu);
         g_wisdom[k] = o;
+        g_wisdom_epoch++;
         loaded++;
     }
     fclose(f);
@@ -1132,6 +1240,7 @@ extern "C" long qsim_tune_table_load(const char *path) {
 extern "C" void qsim_tune_table_clear(void) {
     std::lock_guard<std::mutex> lock(g_wisdom_mu);
     g_wisdom.clear();
+    g_wisdom_epoch++;
 }
 
 extern "C" int qsim_plan_circuit(const qsim_circuit *c, int fuse, int tile_bits, int tile_low_bits, qsim_stats *out) {

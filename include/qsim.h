@@ -61,6 +61,8 @@ enum {
     QSIM_OPT_TILE_THREADS = 8, /* threads per tile workgroup: 0 auto (256 below 2^12 amplitudes, else 512), 256, 512, 1024 */
     QSIM_OPT_DEBUG_SKIP_OPS = 10,/* measurement aid, default 0: 1 = tile passes move their tiles HBM -> LDS -> HBM but apply
                                   * no blocks (amplitudes are then WRONG); splits a pass's memory time from its compute time */
+    QSIM_OPT_PLAN_CACHE = 13,  /* default 1: the plans of the last few flushed gate queues are kept (passes, bit orders, blocks on the
+                                * device); a queue with the same gates is replayed without scheduling or uploads.  0 = plan anew */
     QSIM_OPT_DEBUG_TILE_ORDER = 12,/* measurement aid, default 0: k > 0 = every tile pass walks its high tile bits in a pseudo-random
                                   * order seeded by k (results are unchanged: the order only decides which bits lanes, waves and
                                   * registers walk) */

@@ -753,6 +753,61 @@ def test_geometry_planning_keeps_results_and_fills_the_table(oracle, tmp_path):
     assert lib.qsim_tune_table_size() == 0
 
 
+def test_plan_cache_replays_identical_queues_only(oracle, tmp_path):
+    """QSIM_OPT_PLAN_CACHE: a gate queue that was planned before is replayed from the cached plan (same launches, same
+    amplitudes); a queue that differs in one matrix entry, one qubit or one option is planned anew; the planning step
+    (qsim_tune_circuit) invalidates plans built with older bit orders."""
+    n, depth = 18, 500
+    gates = circuits.random_gates(n, depth, 61, "all")
+    path = circuits.write_qasm(str(tmp_path / "c.qasm"), n, gates)
+    _, want, _, _ = oracle.run_qasm(path)
+    c = Circuit.from_file(path)
+    gates2 = list(gates)
+    gates2[137] = ("rz", 0.123456, 5)
+    path2 = circuits.write_qasm(str(tmp_path / "c2.qasm"), n, gates2)
+    _, want2, _, _ = oracle.run_qasm(path2)
+    c2 = Circuit.from_file(path2)
+    with Simulator(n, fuse=3, profile=True) as sim:
+        logs = []
+        for rep in range(3):
+            sim.reset()
+            sim.reset_stats()
+            sim.run(c)
+            assert np.max(np.abs(sim.read() - want)) < TOL, rep
+            logs.append([(k, nops, hm) for k, nops, hm, _ in sim.launch_log()])
+        assert logs[0] == logs[1] == logs[2] and len(logs[0]) >= 2
+        sim.reset(); sim.run(c2)
+        assert np.max(np.abs(sim.read() - want2)) < TOL          # one gate changed: not the cached plan
+        sim.reset(); sim.run(c)
+        assert np.max(np.abs(sim.read() - want)) < TOL           # and back (both plans are cached now)
+        sim.set_option(_lib.OPT_TILE_BITS, 10)                   # an option that shapes the plan
+        sim.reset(); sim.run(c)
+        assert np.max(np.abs(sim.read() - want)) < TOL
+        sim.set_option(_lib.OPT_TILE_BITS, 12)
+        rep = sim.tune(c, max_candidates=5, budget_ms=0)         # new bit orders: plans built before are stale
+        assert rep["passes_tuned"] >= 1
+        sim.run(c)
+        assert np.max(np.abs(sim.read() - want)) < TOL
+        sim.reset(); sim.run(c)                                  # replay of the plan built after tuning
+        assert np.max(np.abs(sim.read() - want)) < TOL
+        sim.set_option(_lib.OPT_PLAN_CACHE, 0)
+        sim.reset(); sim.run(c)
+        assert np.max(np.abs(sim.read() - want)) < TOL
+        # more distinct queues than the cache holds: eviction, then the first one again
+        sim.set_option(_lib.OPT_PLAN_CACHE, 1)
+        for seed in range(10):
+            g = circuits.random_gates(n, 60, 500 + seed, "all")
+            pth = circuits.write_qasm(str(tmp_path / f"e{seed}.qasm"), n, g)
+            _, w, _, _ = oracle.run_qasm(pth)
+            cc = Circuit.from_file(pth)
+            for _ in range(2):
+                sim.reset(); sim.run(cc)
+                assert np.max(np.abs(sim.read() - w)) < TOL, seed
+        sim.reset(); sim.run(c)
+        assert np.max(np.abs(sim.read() - want)) < TOL
+    _lib.load().qsim_tune_table_clear()
+
+
 def test_randomised_geometry_sweep(oracle, tmp_path):
     """Seeded sweep over register sizes, vocabularies and every engine option (tile size, low bits, ops per pass,
     threads, padding start, grid cap): each case against the oracle.  Catches geometry corner cases (n just above the

@@ -215,7 +215,11 @@ class ShardedSimulator:
                                              "(50 GB/s per link and direction, 2^k - 1 links at once)",
                                     "bytes_sent_per_rank_per_step": bytes_per_rank, "seconds_per_step": seconds}
         self.exchange_backend = "torch.distributed"
-        if self.world > 1 and hasattr(self.shard, "attach_comm") and dist.get_backend() == "nccl":
+        import os
+        # QSIM_EXCHANGE=torch keeps the round-1 form (pack, then torch.distributed send/recv on torch's stream): an
+        # operator's switch for a node where the library's own communicator misbehaves; set it on every rank
+        if (self.world > 1 and hasattr(self.shard, "attach_comm") and dist.get_backend() == "nccl"
+                and os.environ.get("QSIM_EXCHANGE", "") != "torch"):
             self._attach_native_comm()
         if self.exchange_backend == "torch.distributed":
             self._warm_up_links()

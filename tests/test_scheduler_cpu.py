@@ -263,3 +263,56 @@ def test_tile_passes_respect_geometry_limits():
             for o in ops:
                 assert len(mixing(o[3], o[4])) <= 5 and len(o[3]) <= 7
                 assert (o[4] != 0).sum(axis=1).max() <= 4
+
+
+def test_tokenizer_formatting_fuzz_against_the_oracle(oracle, tmp_path):
+    """200 seeded files in the shapes quantum_simulator.c:115-254 accepts — blanks, tabs, CR/LF, commas and semicolons as
+    separators, `q[k]` / `$k` / other register names, both `qubit` spellings, rz angles in several notations, no final
+    newline — parsed by libqsim's tokenizer and by the oracle (the restatement of the reference's fscanf loop): same
+    register size, same gate count, and the parsed gate list replayed with the oracle's kernels reproduces the oracle's
+    own amplitudes bit for bit."""
+    rng = np.random.default_rng(77)
+    names1 = ["x", "sx", "z", "s", "sdg", "t", "tdg", "h"]
+
+    def operand(q):
+        style = rng.integers(0, 4)
+        return [f"q[{q}]", f"${q}", f"reg[{q}]", f"q[ {q}"][style] if style < 3 else f"q[{q}]"
+
+    def angle():
+        v = float(rng.uniform(-3.1, 3.1))
+        return [repr(v), f"{v:.6f}", f"{v:.3e}", f"{v:+.4f}"][rng.integers(0, 4)]
+
+    for case in range(200):
+        n = int(rng.integers(1, 7))
+        eol = "\r\n" if rng.random() < 0.3 else "\n"
+        sep = lambda: [" ", "  ", "\t", " \t "][rng.integers(0, 4)]
+        lines = ["OPENQASM 3.0;", 'include "stdgates.inc";',
+                 (f"qubit[{n}] q;" if rng.random() < 0.5 else f"qubit q[{n}];")]
+        depth = int(rng.integers(1, 40))
+        for _ in range(depth):
+            if n >= 2 and rng.random() < 0.25:
+                a, b = (int(x) for x in rng.choice(n, 2, replace=False))
+                comma = [", ", ",", " , ", " "][rng.integers(0, 4)]
+                stmt = f"cx{sep()}{operand(a)}{comma}{operand(b)}"
+            elif rng.random() < 0.2:
+                stmt = f"rz({angle()}){sep()}{operand(int(rng.integers(0, n)))}"
+            else:
+                stmt = f"{names1[rng.integers(0, len(names1))]}{sep()}{operand(int(rng.integers(0, n)))}"
+            end = [";", "; ", ";;", " ;"][rng.integers(0, 4)]
+            lines.append(stmt + end)
+        text = eol.join(lines) + (eol if rng.random() < 0.8 else "")
+        if rng.random() < 0.2:
+            text = text.replace(eol + "h", eol + eol + "  h", 1)  # blank line and indentation
+        path = tmp_path / "f.qasm"
+        path.write_bytes(text.encode())
+        on, amps, _, gates = oracle.run_qasm(str(path))
+        c = Circuit.from_file(str(path))
+        assert (c.num_qubits, len(c)) == (on, gates), (case, text)
+        s = oracle.zero_state(on)
+        for i in range(len(c)):
+            g = c.gate(i)
+            if g[0] == "cx":
+                oracle.apply_cx(s, on, g[1], g[2])
+            else:
+                oracle.apply_1q(s, on, g[2].T, g[1])
+        assert s.tobytes() == amps.tobytes(), (case, text)

@@ -865,11 +865,15 @@ extern "C" int qsim_rank_comm_exchange(qsim_rank_comm *c, const int *shard_bits,
     const size_t blk_bytes = ((size_t)16 << m) >> k;
     if (hipSetDevice(c->device) != hipSuccess) return cfail(QSIM_ERR_DEVICE, "hipSetDevice failed");
     hipStream_t stream = (hipStream_t)qsim_stream(c->shard);
+    // exchanges are timed (HIP events on the shard's stream) only while the shard is in profile mode, and never more
+    // than a bounded number of them stay unresolved: a long-running program that never asks for the statistics must
+    // not collect events
+    const bool timed = qsim_get_option(c->shard, QSIM_OPT_PROFILE) != 0 && c->timing.size() < 4096;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return cfail(QSIM_ERR_DEVICE, "event creation failed");
+    if (timed && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) return cfail(QSIM_ERR_DEVICE, "event creation failed");
     int rc = qsim_flush(c->shard); // everything queued so far belongs in front of the exchange
     if (rc) return cfail(rc, "%s", qsim_last_error());
-    (void)hipEventRecord(e0, stream);
+    if (timed) (void)hipEventRecord(e0, stream);
     rc = qsim_pack_bits(c->shard, local_bits, k, c->scratch);
     if (rc) return cfail(rc, "%s", qsim_last_error());
     char *state = (char *)qsim_device_ptr(c->shard);
@@ -885,8 +889,10 @@ extern "C" int qsim_rank_comm_exchange(qsim_rank_comm *c, const int *shard_bits,
     if (nr != ncclSuccess) return cfail(QSIM_ERR_DEVICE, "RCCL exchange failed: %s", ncclGetErrorString(nr));
     if (hipMemcpyAsync(state + (size_t)mine * blk_bytes, scr + (size_t)mine * blk_bytes, blk_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess)
         return cfail(QSIM_ERR_DEVICE, "exchange copy failed");
-    (void)hipEventRecord(e1, stream);
-    c->timing.emplace_back(e0, e1);
+    if (timed) {
+        (void)hipEventRecord(e1, stream);
+        c->timing.emplace_back(e0, e1);
+    }
     c->exchanges++;
     c->bytes_sent += (double)blk_bytes * ((1 << k) - 1);
     return QSIM_OK;

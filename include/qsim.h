@@ -259,7 +259,8 @@ int qsim_shard_plan_predict(const qsim_shard_plan *p, double link_gbps, double p
  * Rank 0 calls qsim_rccl_unique_id and hands the QSIM_RCCL_ID_BYTES bytes to every rank over the launcher's own channel;
  * each rank then joins with qsim_rank_comm_create (scratch: a caller-owned device buffer as large as the shard, or NULL
  * to let the library allocate one).  qsim_rank_comm_exchange = pack kernel + ONE ncclGroup on the shard's stream, no
- * host synchronisation; qsim_rank_comm_stats reports the HIP-event time its stream spent in exchanges. */
+ * host synchronisation; qsim_rank_comm_stats reports the HIP-event time its stream spent in exchanges (measured while
+ * the shard is in profile mode, QSIM_OPT_PROFILE). */
 #define QSIM_RCCL_ID_BYTES 128
 typedef struct qsim_rank_comm qsim_rank_comm;
 int qsim_rccl_unique_id(void *id_bytes);

@@ -405,7 +405,7 @@ static SchedConfig sched_config(int n, int fuse, int tile_bits, int tile_low_bit
     if (fuse >= 3 && size_class >= 28) {
         c.local_iters = 3;
         c.lookahead = 1;
-        if (tile_max_ops == 32) c.tile_max_ops = 24; // 32 = the option's default, i.e. not chosen by the caller
+        if (tile_max_ops == 32) { c.tile_max_ops = 24; c.tail_max_ops = 32; } // 32 = the option's default, i.e. not chosen by the caller
     }
     return c;
 }

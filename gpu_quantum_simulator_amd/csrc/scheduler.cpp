@@ -417,6 +417,25 @@ void Scheduler::single_op_pass(const FusedOp &op, const PassSink &sink) const {
         sink(std::move(p));
     } else {
         if (op.is_identity()) return;
+        // a pair cluster that is still exactly one CX (nothing else was folded into it) moves half the state, not all
+        // of it: the swap kernel instead of the dense 4x4 (or a tile pass)
+        for (int hi_ctl = 0; hi_ctl < 2; hi_ctl++) {
+            cd ref[16];
+            cx4(hi_ctl != 0, ref);
+            bool same = true;
+            for (int k = 0; k < 16 && same; k++) same = op.m[k] == ref[k];
+            if (!same) continue;
+            FusedOp cx;
+            cx.kind = OP_CX;
+            cx.q_hi = hi_ctl ? op.q_hi : op.q_lo; // control
+            cx.q_lo = hi_ctl ? op.q_lo : op.q_hi; // target
+            cx.gates = op.gates;
+            p.ops[0] = cx;
+            p.kclass = QSIM_K_CX;
+            p.bytes = S;
+            sink(std::move(p));
+            return;
+        }
         if (op.kind == OP_G2 && op.q_lo >= 6) {
             p.kclass = QSIM_K_GATE2;
             p.bytes = 2 * S;
@@ -513,6 +532,7 @@ void Scheduler::build_passes(const PassSink &sink) {
         must[i] = cfg_.selectors ? (qm[i] & ~closed_[i].selector_mask()) : qm[i];
     }
     std::vector<char> done(m, 0), trial;
+    int cap = cfg_.tile_max_ops; // clusters per pass; lifted to tail_max_ops when that lets a pass finish the circuit
     size_t first = 0;
     std::vector<FusedOp> group;
     struct Cand { long idx; int need; };
@@ -544,7 +564,7 @@ void Scheduler::build_passes(const PassSink &sink) {
     // how many blocks a pass reaches when it is finished greedily from (dn, hset)
     auto rollout = [&](std::vector<char> &dn, size_t from, size_t to, uint64_t hset, int have) {
         int cnt = 0;
-        while (have + cnt < cfg_.tile_max_ops) {
+        while (have + cnt < cap) {
             const Cand c = scan(dn, from, to, hset, nullptr);
             if (c.idx < 0) break;
             dn[(size_t)c.idx] = 1;
@@ -555,7 +575,7 @@ void Scheduler::build_passes(const PassSink &sink) {
         for (int extra = 0; extra < cfg_.lookahead; extra++) {
             uint64_t h2 = 0;
             int c2 = 0;
-            while (c2 < cfg_.tile_max_ops) {
+            while (c2 < cap) {
                 const Cand c = scan(dn, from, to, h2, nullptr);
                 if (c.idx < 0) break;
                 dn[(size_t)c.idx] = 1;
@@ -575,7 +595,7 @@ void Scheduler::build_passes(const PassSink &sink) {
         uint64_t blocked = 0;
         int score = 0, cnt = 0;
         if (out) out->clear();
-        for (size_t i = from; i < to && cnt < cfg_.tile_max_ops; i++) {
+        for (size_t i = from; i < to && cnt < cap; i++) {
             if (dn[i]) continue;
             if (!(qm[i] & blocked) && !(must[i] & ~lowmask & ~S)) {
                 score += cfg_.objective ? (int)closed_[i].gates : 1;
@@ -588,13 +608,40 @@ void Scheduler::build_passes(const PassSink &sink) {
         }
         return score;
     };
+    // greedy passes needed to finish everything pending in [from, to) (at most `limit` are tried)
+    auto passes_to_finish = [&](std::vector<char> &dn, size_t from, size_t to, int limit) {
+        int n_pass = 0;
+        for (; n_pass < limit; n_pass++) {
+            bool pending = false;
+            for (size_t i = from; i < to && !pending; i++) pending = !dn[i];
+            if (!pending) break;
+            uint64_t h2 = 0;
+            int c2 = 0;
+            while (c2 < cap) {
+                const Cand c = scan(dn, from, to, h2, nullptr);
+                if (c.idx < 0) break;
+                dn[(size_t)c.idx] = 1;
+                h2 |= must[(size_t)c.idx] & ~lowmask;
+                c2++;
+            }
+            if (c2 == 0) return limit; // cannot happen (a pass always takes something); keeps the loop finite
+        }
+        return n_pass;
+    };
     auto eval_ahead = [&](size_t from, size_t to, uint64_t S, std::vector<long> *out) {
         int score = eval(done, from, to, S, out ? out : &picks);
         if (cfg_.lookahead > 0 || endgame) {
             trial = done;
             for (long i : (out ? *out : picks)) trial[(size_t)i] = 1;
             std::vector<char> t2 = trial;
-            score += rollout(t2, from, to, 0, 0) ; // the next pass, built greedily (plus cfg_.lookahead - 1 more inside)
+            if (endgame) {
+                // near the end what counts is how many MORE sweeps over the state the circuit needs (a straggler pass for
+                // a handful of gates costs as much as a full one): fewer first, then more clusters in this pass
+                const int more = passes_to_finish(t2, from, to, 8);
+                score += (8 - more) * 100000;
+            } else {
+                score += rollout(t2, from, to, 0, 0); // the next pass, built greedily (plus cfg_.lookahead more inside)
+            }
         }
         return score;
     };
@@ -604,11 +651,17 @@ void Scheduler::build_passes(const PassSink &sink) {
         if (done[first]) { first++; continue; }
         group.clear();
         uint64_t hset = 0;
+        {   // the cap balances a pass's block phase against its memory time; a pass that would leave only a few clusters
+            // for one more sweep over the state (6.6 ms at n = 30 for, on the bench circuit, ONE gate) takes them instead
+            size_t left = 0;
+            for (size_t i = first; i < m && left <= (size_t)std::max(cfg_.tail_max_ops, cfg_.tile_max_ops); i++) left += !done[i];
+            cap = (cfg_.tail_max_ops > cfg_.tile_max_ops && left <= (size_t)cfg_.tail_max_ops) ? cfg_.tail_max_ops : cfg_.tile_max_ops;
+        }
         const size_t end = std::min(m, first + (size_t)cfg_.window);
         // 1. greedy construction on a copy: cheapest new qubit first, ties broken by a rollout
         std::vector<char> work = done;
         int have = 0;
-        while (have < cfg_.tile_max_ops) {
+        while (have < cap) {
             cands.clear();
             Cand pick = scan(work, first, end, hset, cfg_.rollout > 1 ? &cands : nullptr);
             if (pick.idx < 0) break;

@@ -115,6 +115,7 @@ struct SchedConfig {
     int tile_bits = 12;
     int tile_low_bits = 3;
     int tile_max_ops = 32;
+    int tail_max_ops = 0;  // > tile_max_ops: the cap of a pass that can take ALL remaining clusters (no straggler pass for a handful of gates)
     int window = 512;  // clusters scanned ahead when grouping a pass
     int merge = 1;     // level 3: merge neighbouring blocks of a pass into sparse blocks of up to merge_qubits tile qubits
     int merge_qubits = 5;

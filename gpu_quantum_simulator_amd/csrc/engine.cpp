@@ -506,7 +506,7 @@ static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, int a
             t.rowoff[v][p] = slot_off(r) << amp_shift;
             for (int j = 0; j < T; j++) {
                 const int col = ccols[v][c0 + j];
-                t.off[v][p * T + j] = slot_off(col) << amp_shift;
+                t.off[v][c0 + j] = slot_off(col) << amp_shift; // the same list from every row of the class
                 put(v, p * T + j, blk.at(v, r, col)); // exact zero where the row does not use the column
             }
             if (row.n == 1 && row.col[0] == r && is1(row.val[0])) t.meta[v] |= 1u << p; // identity row

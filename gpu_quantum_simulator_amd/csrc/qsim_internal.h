@@ -25,7 +25,7 @@ struct M4 { double re[16], im[16]; };
 //              costs T LDS reads for T outputs — ONE read per amplitude whatever T is (the first version read every
 //              row's operands separately: T reads per amplitude; the block phase of a pass is LDS-bound, so that
 //              was a third of its time):
-//                  x[j] = slot off[bank][(cT)*T + j]           (taken from the class's first row: all rows carry the same list)
+//                  x[j] = slot off[bank][cT + j]               (one operand list per class)
 //                  y[cT+i] = sum_j coef[bank][(cT+i)*T + j] * x[j]     -> written to slot rowoff[bank][cT+i]
 //              Offsets are ready LDS byte offsets (wave-uniform, layout swizzle applied).  meta[bank] bit p: position p is
 //              an identity row; a class whose T rows all are costs nothing (identity rows are packed together).
@@ -46,20 +46,26 @@ constexpr int kMaxBanks = 4;
 constexpr int kMaxOpQ = 5;                      // TOP_SP blocks span 2..5 tile qubits
 constexpr int kMaxOpEntries = 4 << kMaxOpQ;     // 4 entries for each of 32 rows
 struct TileOp {
-    int32_t kind;
-    int32_t nq;           // qubits of the block inside the tile (0..5)
-    int32_t b[kMaxOpQ];   // tile-local bits, ascending
-    int32_t terms;        // TOP_SP: T = rows per class = entries per row (1, 2, 4), the same for every bank
-    int32_t nsel;         // 0..2 selecting qubits
-    int32_t selbit[2];    // their global index bits, most significant bank bit first
-    int32_t ident;
-    uint32_t meta[kMaxBanks];
+    // 64-byte header; the kernel fetches its first 32 bytes with ONE scalar load (s_load_dwordx8) and decodes them with
+    // scalar bit-field extracts, one block ahead of the block it is working on — read field by field, the dispatch was a
+    // chain of six dependent scalar-load round trips per block and wave (kind -> selectors -> bank -> identity -> shape ->
+    // tile bits) before the first LDS read could be issued.
+    uint8_t kind;         // dword 0
+    uint8_t nq;           //   qubits of the block inside the tile (0..5)
+    uint8_t terms;        //   TOP_SP: T = rows per class = entries per row (1, 2, 4), the same for every bank
+    uint8_t nsel;         //   0..2 selecting qubits
+    uint8_t selbit[2];    // dword 1: their global index bits, most significant bank bit first
+    uint8_t ident;        //   bit v: bank v is the identity
+    uint8_t pad0;
+    uint8_t b[8];         // dwords 2-3: tile-local bits of the block's qubits, ascending (kMaxOpQ used)
+    uint32_t meta[kMaxBanks]; // dwords 4-7
+    uint32_t pad1[8];
     uint32_t rowoff[kMaxBanks][1 << kMaxOpQ]; // TOP_SP: LDS BYTE offset of the slot position p writes (class order differs per bank)
-    uint32_t off[kMaxBanks][kMaxOpEntries];   // TOP_SP: LDS BYTE offset of entry e's operand slot
-    double re[kMaxBanks][kMaxOpEntries];
+    uint32_t off[kMaxBanks][1 << kMaxOpQ];    // TOP_SP: LDS BYTE offset of operand j of class c at [c*T + j] (one list per class)
+    double re[kMaxBanks][kMaxOpEntries];      // entry j of position p at [p*T + j]
     double im[kMaxBanks][kMaxOpEntries];
 };
-static_assert(sizeof(TileOp) == 64 + 4 * 128 + 2048 + 8192, "TileOp layout is shared with the device");
+static_assert(sizeof(TileOp) == 64 + 4 * 128 + 4 * 128 + 8192 && offsetof(TileOp, meta) == 16 && offsetof(TileOp, rowoff) == 64, "TileOp layout is shared with the device");
 
 constexpr int kMaxTileHigh = 10; // high (non-contiguous) qubits per tile
 struct TileGeom {

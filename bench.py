@@ -50,6 +50,8 @@ def parse_args(argv=None):
     ap.add_argument("--tile-max-ops", type=int, default=None)
     ap.add_argument("--grid-cap", type=int, default=None)
     ap.add_argument("--tile-threads", type=int, default=None)
+    ap.add_argument("--pingpong", type=int, default=None, choices=[0, 1, 2],
+                    help="QSIM_OPT_PINGPONG: tile passes out of place between two buffers (default: the library's, 1 = from 1 GiB of state)")
     ap.add_argument("--probe", type=int, default=None, metavar="Q",
                     help="single-qubit roofline probe instead of the random circuit: `depth` h gates on qubit Q, fusion off")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
@@ -338,7 +340,7 @@ def main():
     seed = args.seed if args.seed is not None else 20240117 + n
     opts = {k: v for k, v in (("tile_bits", args.tile_bits), ("tile_low_bits", args.tile_low_bits),
                               ("tile_max_ops", args.tile_max_ops), ("grid_cap", args.grid_cap),
-                              ("tile_threads", args.tile_threads)) if v is not None}
+                              ("tile_threads", args.tile_threads), ("pingpong", args.pingpong)) if v is not None}
     head = b.measure(n, args.depth, args.vocabulary, seed, args.steps, args.warmup, args.fuse, opts,
                      probe_q=args.probe, with_1q_probe=True)
 

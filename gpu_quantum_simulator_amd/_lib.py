@@ -18,6 +18,7 @@ OPT_DEBUG_SKIP_OPS = 10
 OPT_DEBUG_SKIP_MEM = 11
 OPT_DEBUG_TILE_ORDER = 12
 OPT_PLAN_CACHE = 13
+OPT_PINGPONG = 14
 K_NAMES = ("init", "gate1", "gate1_lo", "phase", "cx", "gate2", "tile", "pack")
 K_COUNT = len(K_NAMES)
 
@@ -77,6 +78,7 @@ SIGNATURES = {
     "qsim_pack_bits": (c_int, [c_void_p, POINTER(c_int), c_int, c_void_p]),
     "qsim_pack_bits_to": (c_int, [c_void_p, POINTER(c_int), c_int, POINTER(c_void_p)]),
     "qsim_swap_buffer": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "qsim_set_spare_buffer": (c_int, [c_void_p, c_void_p]),
     "qsim_block_prob_masked": (c_int, [c_void_p, c_uint64, c_uint64, _DP]),
     "qsim_gather_masked": (c_int, [c_void_p, c_uint64, c_uint64, _DP]),
     "qsim_scale": (c_int, [c_void_p, c_double, c_double]),

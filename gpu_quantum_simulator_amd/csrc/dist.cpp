@@ -341,6 +341,9 @@ extern "C" int qsim_cluster_create(qsim_cluster **out, int num_q, int num_shards
                 qsim_cluster_destroy(c);
                 return cfail(QSIM_ERR_DEVICE, "ncclCommInitAll failed: %s", ncclGetErrorString(nr));
             }
+            // A shard's scratch is touched by its own stream only in this mode (pack, then the sends): idle during local
+            // steps, so it doubles as the second buffer of the shard's out-of-place tile passes (QSIM_OPT_PINGPONG).
+            for (int r = 0; r < num_shards; r++) (void)qsim_set_spare_buffer(c->shard[r], c->scratch[r]);
         }
     }
     *out = c;

@@ -90,6 +90,14 @@ struct qsim_state {
     void *amps = nullptr; // 2^n amplitudes: (re, im) pairs of double (16 B) or, with f32, of float (8 B)
     bool f32 = false;
     bool owns = false;
+    // Second buffer of the same size for out-of-place tile passes (QSIM_OPT_PINGPONG; k_tile comment): a pass reads
+    // `amps` and writes `spare`, then the two swap.  Within one qsim_flush an even number of passes run that way, so the
+    // state is back in the buffer it started from when the flush returns (qsim_device_ptr stays what it was, an external
+    // buffer holds the result).  Allocated on first use for states that own their buffer, or lent by the caller
+    // (qsim_set_spare_buffer: a sharded run lends its exchange scratch, which is idle between exchanges).
+    void *spare = nullptr;
+    bool owns_spare = false, spare_failed = false;
+    int pingpong = 1; // 0 never, 1 when the state is large enough to pay (kPingPongMinBytes), 2 whenever a second buffer can be had
     size_t amp_bytes() const { return f32 ? 8 : 16; }
     // options
     int fuse = 3, profile = 0, tile_bits = 12, tile_low_bits = 3, tile_max_ops = 32, grid_cap = 0, tile_threads = 0, tile_pad_from = 10, debug_skip_ops = 0, debug_skip_mem = 0, debug_tile_order = 0;
@@ -170,6 +178,7 @@ extern "C" void qsim_destroy(qsim_state *s) {
     for (CachedPlan &pl : s->plans)
         if (pl.d_ops) (void)hipFree(pl.d_ops);
     if (s->owns && s->amps) (void)hipFree(s->amps);
+    if (s->owns_spare && s->spare) (void)hipFree(s->spare);
     if (s->d_ops) (void)hipFree(s->d_ops);
     if (s->h_ops) (void)hipHostFree(s->h_ops);
     if (s->d_scalar) (void)hipFree(s->d_scalar);
@@ -235,6 +244,11 @@ extern "C" int qsim_set_option(qsim_state *s, int option, long value) {
     case QSIM_OPT_PLAN_CACHE:
         s->plan_cache = value != 0;
         break;
+    case QSIM_OPT_PINGPONG:
+        if (value < 0 || value > 2) return fail(QSIM_ERR_ARG, "pingpong must be 0 (never), 1 (auto) or 2 (always)");
+        s->pingpong = (int)value;
+        s->spare_failed = false;
+        break;
 
     case QSIM_OPT_TILE_THREADS:
         if (value != 0 && value != 256 && value != 512 && value != 1024)
@@ -262,6 +276,7 @@ extern "C" long qsim_get_option(const qsim_state *s, int option) {
     case QSIM_OPT_DEBUG_SKIP_MEM: return s->debug_skip_mem;
     case QSIM_OPT_DEBUG_TILE_ORDER: return s->debug_tile_order;
     case QSIM_OPT_PLAN_CACHE: return s->plan_cache;
+    case QSIM_OPT_PINGPONG: return s->pingpong;
     default: return -1;
     }
 }
@@ -565,25 +580,47 @@ static void order_tile_bits(qsim_state *s, TileGeom &g) {
         for (int j = 0; j < g.n_high; j++) g.high[j] = it->second.high[j];
 }
 
-// Launches a tile pass whose TileOps are already on the device (no statistics, no profiling events).
-static int launch_tile_prepared(qsim_state *s, const TileGeom &geom, const TileOp *d, int need, bool from_zero_ket) {
+// The second buffer for out-of-place tile passes, or NULL when the passes of this state run in place.
+constexpr size_t kPingPongMinBytes = (size_t)1 << 30;
+static void *spare_buffer(qsim_state *s) {
+    const size_t bytes = s->amp_bytes() << s->n;
+    if (s->pingpong == 0 || (s->pingpong == 1 && bytes < kPingPongMinBytes)) return nullptr;
+    if (s->spare) return s->spare;
+    if (!s->owns || s->spare_failed) return nullptr; // an external buffer is only ever paired with a lent one
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + total_b / 16 ||
+        hipMalloc(&s->spare, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        s->spare = nullptr;
+        s->spare_failed = true; // not enough memory for two copies: stay in place, do not ask again
+        return nullptr;
+    }
+    s->owns_spare = true;
+    return s->spare;
+}
+
+// Launches a tile pass whose TileOps are already on the device (no statistics, no profiling events).  oop: write the
+// state to the spare buffer and make that the state (the caller checked spare_buffer()).
+static int launch_tile_prepared(qsim_state *s, const TileGeom &geom, const TileOp *d, int need, bool from_zero_ket, bool oop = false) {
     LaunchCfg cfg{s->stream, s->grid_cap};
     const int threads = s->tile_threads; // 0: default for the tile size
+    void *out = oop ? s->spare : s->amps;
     hipError_t e;
     if (s->debug_skip_ops) {
         TileGeom bare = geom;
         bare.n_scale = 0;
-        e = launch_tile(cfg, s->amps, s->f32, bare, d, 0, threads, from_zero_ket, s->zero_ket_amp);
+        e = launch_tile(cfg, s->amps, out, s->f32, bare, d, 0, threads, from_zero_ket, s->zero_ket_amp);
     } else {
-        e = launch_tile(cfg, s->amps, s->f32, geom, d, need, threads, from_zero_ket, s->zero_ket_amp, s->debug_skip_mem != 0);
+        e = launch_tile(cfg, s->amps, out, s->f32, geom, d, need, threads, from_zero_ket, s->zero_ket_amp, s->debug_skip_mem != 0);
     }
     if (e != hipSuccess) return fail(QSIM_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+    if (oop) std::swap(s->amps, s->spare);
     return QSIM_OK;
 }
 
 // Prepares the blocks of a tile pass for the given bit order in the pinned ring, uploads and launches them; `capture`
 // (optional) receives a copy of the prepared TileOps for the plan cache.
-static int launch_tile_pass(qsim_state *s, const Pass &p, const TileGeom &geom, bool from_zero_ket, std::vector<TileOp> *capture = nullptr) {
+static int launch_tile_pass(qsim_state *s, const Pass &p, const TileGeom &geom, bool from_zero_ket, std::vector<TileOp> *capture = nullptr, bool oop = false) {
     const size_t need = p.blocks.size();
     if (need > s->ops_cap) return fail(QSIM_ERR_ARG, "tile pass with %zu ops exceeds the op buffer", need);
     if (s->ops_used + need > s->ops_cap) { // ring is full: wait until earlier passes have read their ops
@@ -605,13 +642,13 @@ static int launch_tile_pass(qsim_state *s, const Pass &p, const TileGeom &geom, 
     TileOp *d = s->d_ops + s->ops_used;
     HIP_TRY(hipMemcpyAsync(d, h, need * sizeof(TileOp), hipMemcpyHostToDevice, s->stream));
     s->ops_used += need;
-    return launch_tile_prepared(s, geom, d, (int)need, from_zero_ket);
+    return launch_tile_prepared(s, geom, d, (int)need, from_zero_ket, oop);
 }
 
 // cached_geom / cached_ops: replay of a cached plan (the tile pass's order and device-resident TileOps);
 // capture / geom_out: the first run of a plan records them.
 static int launch_pass(qsim_state *s, const Pass &p, const TileGeom *cached_geom = nullptr, const TileOp *cached_ops = nullptr,
-                       std::vector<TileOp> *capture = nullptr, TileGeom *geom_out = nullptr) {
+                       std::vector<TileOp> *capture = nullptr, TileGeom *geom_out = nullptr, bool oop = false) {
     const bool from_zero_ket = s->zero_ket_pending && p.kclass == QSIM_K_TILE;
     if (s->zero_ket_pending && !from_zero_ket) {
         const int rc = materialize_zero_ket(s);
@@ -658,8 +695,8 @@ static int launch_pass(qsim_state *s, const Pass &p, const TileGeom *cached_geom
         uint64_t hm = 0, oc = 0;
         for (int j = 0; j < geom.n_high; j++) { hm |= 1ULL << geom.high[j]; oc |= (uint64_t)geom.high[j] << (5 * j); }
         LaunchScope scope(s, p.kclass, (int)p.blocks.size(), hm, oc);
-        const int rc = cached_ops ? launch_tile_prepared(s, geom, cached_ops, (int)p.blocks.size(), from_zero_ket)
-                                  : launch_tile_pass(s, p, geom, from_zero_ket, capture);
+        const int rc = cached_ops ? launch_tile_prepared(s, geom, cached_ops, (int)p.blocks.size(), from_zero_ket, oop)
+                                  : launch_tile_pass(s, p, geom, from_zero_ket, capture, oop);
         if (rc) return rc;
         break;
     }
@@ -702,9 +739,19 @@ extern "C" int qsim_flush(qsim_state *s) {
             if (pl.key != key || pl.wisdom_epoch != epoch) continue;
             pl.last_use = ++s->plan_clock;
             s->queue.clear();
+            // out-of-place tile passes come in pairs (the state ends where it started): with an odd count the last one stays in place
+            size_t tiles = 0, seen = 0;
+            for (const Pass &p : pl.passes) tiles += p.kclass == QSIM_K_TILE;
+            const bool pp = tiles >= 2 && spare_buffer(s) != nullptr;
             for (size_t i = 0; i < pl.passes.size(); i++) {
                 const Pass &p = pl.passes[i];
-                const int rc = p.kclass == QSIM_K_TILE ? launch_pass(s, p, &pl.geoms[i], pl.d_ops + pl.op_first[i]) : launch_pass(s, p);
+                int rc;
+                if (p.kclass == QSIM_K_TILE) {
+                    seen++;
+                    rc = launch_pass(s, p, &pl.geoms[i], pl.d_ops + pl.op_first[i], nullptr, nullptr, pp && !(seen == tiles && (tiles & 1)));
+                } else {
+                    rc = launch_pass(s, p);
+                }
                 if (rc) return rc;
             }
             return QSIM_OK;
@@ -720,15 +767,35 @@ extern "C" int qsim_flush(qsim_state *s) {
     int rc = QSIM_OK;
     CachedPlan fresh;
     std::vector<TileOp> host_ops;
-    sched.finish([&](Pass &&p) { // launched as soon as it is scheduled: the GPU works while later passes are planned
+    auto launch = [&](Pass &&p, bool oop) {
         if (rc != QSIM_OK) return;
-        if (!cacheable) { rc = launch_pass(s, p); return; }
+        if (!cacheable) { rc = launch_pass(s, p, nullptr, nullptr, nullptr, nullptr, oop); return; }
         TileGeom g = p.geom;
         fresh.op_first.push_back(host_ops.size());
-        rc = launch_pass(s, p, nullptr, nullptr, &host_ops, &g);
+        rc = launch_pass(s, p, nullptr, nullptr, &host_ops, &g, oop);
         fresh.geoms.push_back(g);
         fresh.passes.push_back(std::move(p));
+    };
+    // Passes are launched as soon as they are scheduled — the GPU works while later passes are planned — except that
+    // with two buffers the most recent tile pass (and whatever followed it) is held back until the next tile pass
+    // arrives: only then is it known not to be the last one, which must bring the state back to its own buffer.
+    void *const home = s->amps;
+    const bool pp = spare_buffer(s) != nullptr;
+    std::vector<Pass> held; // a tile pass, then the non-tile passes scheduled after it
+    auto release = [&](bool last) {
+        for (size_t i = 0; i < held.size(); i++)
+            launch(std::move(held[i]), i == 0 && (!last || s->amps != home)); // the last tile pass: out of place only if that leads home
+        held.clear();
+    };
+    sched.finish([&](Pass &&p) {
+        if (rc != QSIM_OK) return;
+        if (!pp) { launch(std::move(p), false); return; }
+        if (p.kclass == QSIM_K_TILE) release(false);
+        if (p.kclass == QSIM_K_TILE || !held.empty()) held.push_back(std::move(p));
+        else launch(std::move(p), false);
     });
+    release(true);
+    if (s->amps != home) std::swap(s->amps, s->spare); // only after a failed launch: the buffers keep their roles
     if (rc != QSIM_OK || !cacheable || host_ops.size() > kMaxCachedOps) return rc;
     // keep the plan: its TileOps move to a device buffer of their own (one copy, ordered behind the launches above)
     if (!host_ops.empty()) {
@@ -998,6 +1065,26 @@ extern "C" int qsim_swap_buffer(qsim_state *s, void **buffer) {
     void *old = s->amps;
     s->amps = *buffer;
     *buffer = old;
+    if (s->spare == s->amps && !s->owns_spare) s->spare = old; // a lent spare that just became the state: the old state takes its place
+    return QSIM_OK;
+}
+
+// Lends the state a second buffer of 2^n amplitudes on its device for out-of-place tile passes (QSIM_OPT_PINGPONG); the
+// caller keeps ownership and may use the buffer itself whenever no gates are pending (after qsim_flush / qsim_sync the
+// state is in its own buffer and the lent one holds garbage).  NULL takes it back.
+extern "C" int qsim_set_spare_buffer(qsim_state *s, void *buffer) {
+    if (!s) return fail(QSIM_ERR_ARG, "NULL state");
+    const int rc = qsim_flush(s);
+    if (rc) return rc;
+    if (buffer == s->amps) return fail(QSIM_ERR_ARG, "set_spare_buffer: that is the state's own buffer");
+    if (s->owns_spare && s->spare) {
+        HIP_TRY(hipSetDevice(s->device));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        (void)hipFree(s->spare);
+    }
+    s->spare = buffer;
+    s->owns_spare = false;
+    s->spare_failed = false;
     return QSIM_OK;
 }
 
@@ -1122,9 +1209,11 @@ extern "C" int qsim_tune_circuit(qsim_state *s, const qsim_circuit *c, int max_c
     auto elapsed_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     const int saved_skip_mem = s->debug_skip_mem;
     s->debug_skip_mem = 0;
+    void *const home = s->amps;
+    const bool tune_oop = !todo.empty() && spare_buffer(s) != nullptr;
     auto timed = [&](const Pass &p, const TileGeom &g, float &ms) -> int {
         (void)hipEventRecord(e0, s->stream);
-        const int rc2 = launch_tile_pass(s, p, g, false);
+        const int rc2 = launch_tile_pass(s, p, g, false, nullptr, tune_oop); // timed the way most passes of a run go
         if (rc2) return rc2;
         (void)hipEventRecord(e1, s->stream);
         if (hipEventSynchronize(e1) != hipSuccess) return fail(QSIM_ERR_DEVICE, "tuning: event sync failed");
@@ -1173,6 +1262,7 @@ extern "C" int qsim_tune_circuit(qsim_state *s, const qsim_circuit *c, int max_c
     }
     s->debug_skip_mem = saved_skip_mem;
     (void)hipStreamSynchronize(s->stream);
+    if (s->amps != home) std::swap(s->amps, s->spare); // contents are scratch here (reset below); the buffers keep their roles
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     r.seconds = elapsed_ms() * 1e-3;

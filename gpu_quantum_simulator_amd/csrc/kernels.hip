@@ -58,9 +58,9 @@ hipError_t launch_diag1_full(const LaunchCfg &cfg, void *v, bool f32, int n, int
 }
 hipError_t launch_cx(const LaunchCfg &cfg, void *v, bool f32, int n, int control, int target) { return QSIM_DISPATCH(launch_cx(cfg, v, n, control, target)); }
 hipError_t launch_gate2(const LaunchCfg &cfg, void *v, bool f32, int n, int q_hi, int q_lo, const M4 &U) { return QSIM_DISPATCH(launch_gate2(cfg, v, n, q_hi, q_lo, U)); }
-hipError_t launch_tile(const LaunchCfg &cfg, void *v, bool f32, const TileGeom &g, const TileOp *d_ops, int n_ops, int threads, bool from_zero_ket,
+hipError_t launch_tile(const LaunchCfg &cfg, void *v, void *vout, bool f32, const TileGeom &g, const TileOp *d_ops, int n_ops, int threads, bool from_zero_ket,
                        double amp0, bool nomem) {
-    return QSIM_DISPATCH(launch_tile(cfg, v, g, d_ops, n_ops, threads, from_zero_ket, amp0, nomem));
+    return QSIM_DISPATCH(launch_tile(cfg, v, vout, g, d_ops, n_ops, threads, from_zero_ket, amp0, nomem));
 }
 hipError_t launch_norm2(const LaunchCfg &cfg, const void *v, bool f32, int n, double *d_out) { return QSIM_DISPATCH(launch_norm2(cfg, v, n, d_out)); }
 hipError_t launch_block_prob(const LaunchCfg &cfg, const void *v, bool f32, int n, int block_bits, double *d_out) {

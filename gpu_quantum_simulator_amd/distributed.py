@@ -137,6 +137,9 @@ class HipShard:
         self.state = torch.empty((1 << m, 2), dtype=torch.float64, device=self.dev)
         self.scratch = torch.empty((1 << m, 2), dtype=torch.float64, device=self.dev)
         self.sim = Simulator(m, device, fuse=fuse, profile=profile, external_ptr=self.state.data_ptr(), **opts)
+        # the exchange scratch is idle during local steps: lent to the engine as the second buffer of its out-of-place
+        # tile passes (QSIM_OPT_PINGPONG); after every flush the state is back in `state` and the scratch is ours again
+        self.sim.set_spare_buffer(self.scratch.data_ptr())
         self._plan = None
         self.device_index = device
         self.comm = None  # RankComm: the exchanges on RCCL, issued by libqsim on the engine's own stream

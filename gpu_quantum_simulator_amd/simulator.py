@@ -162,7 +162,8 @@ class Simulator:
                  "max_pending": _lib.OPT_MAX_PENDING, "tile_max_ops": _lib.OPT_TILE_MAX_OPS,
                  "grid_cap": _lib.OPT_GRID_CAP, "tile_threads": _lib.OPT_TILE_THREADS,
                  "tile_pad_from": _lib.OPT_TILE_PAD_FROM, "debug_skip_ops": _lib.OPT_DEBUG_SKIP_OPS,
-                 "debug_skip_mem": _lib.OPT_DEBUG_SKIP_MEM, "debug_tile_order": _lib.OPT_DEBUG_TILE_ORDER, "plan_cache": _lib.OPT_PLAN_CACHE}
+                 "debug_skip_mem": _lib.OPT_DEBUG_SKIP_MEM, "debug_tile_order": _lib.OPT_DEBUG_TILE_ORDER, "plan_cache": _lib.OPT_PLAN_CACHE,
+                 "pingpong": _lib.OPT_PINGPONG}
         # tile_low_bits first when shrinking, tile_bits first when growing: keep every intermediate valid
         for key in sorted(options, key=lambda k: k != "tile_low_bits"):
             self.set_option(names[key], options[key])
@@ -219,6 +220,10 @@ class Simulator:
         arr = (c_int * len(bits))(*bits)
         ptrs = (c_void_p * len(dst_ptrs))(*dst_ptrs)
         check(_lib.load().qsim_pack_bits_to(self._h, arr, len(bits), ptrs))
+
+    def set_spare_buffer(self, ptr: Optional[int]):
+        """qsim_set_spare_buffer: lends the state a second device buffer for out-of-place tile passes (None takes it back)."""
+        check(_lib.load().qsim_set_spare_buffer(self._h, c_void_p(ptr or 0)))
 
     def swap_buffer(self, ptr: int) -> int:
         """qsim_swap_buffer: the state takes `ptr` as its amplitude buffer; returns the buffer it held before."""

@@ -63,6 +63,10 @@ enum {
                                   * no blocks (amplitudes are then WRONG); splits a pass's memory time from its compute time */
     QSIM_OPT_PLAN_CACHE = 13,  /* default 1: the plans of the last few flushed gate queues are kept (passes, bit orders, blocks on the
                                 * device); a queue with the same gates is replayed without scheduling or uploads.  0 = plan anew */
+    QSIM_OPT_PINGPONG = 14,    /* tile passes out of place: each reads the state from one buffer and writes it to a second one, and the
+                                * two swap (an even number of times per flush: the state is back in its own buffer afterwards).  The
+                                * same bytes move ~5 % faster than in place at n = 30.  0 never, 1 (default) for states of >= 1 GiB
+                                * when the second buffer fits (allocated on first use, or lent with qsim_set_spare_buffer), 2 always */
     QSIM_OPT_DEBUG_TILE_ORDER = 12,/* measurement aid, default 0: k > 0 = every tile pass walks its high tile bits in a pseudo-random
                                   * order seeded by k (results are unchanged: the order only decides which bits lanes, waves and
                                   * registers walk) */
@@ -192,6 +196,10 @@ int qsim_pack_bits(qsim_state *s, const int *bits, int nbits, void *dst_device);
  * spare buffer (now holding the shard's new contents) the state and hands back the old one. */
 int qsim_pack_bits_to(qsim_state *s, const int *bits, int nbits, void *const *dst_blocks);
 int qsim_swap_buffer(qsim_state *s, void **buffer_device);
+/* Lends the state a second device buffer of 2^n amplitudes for out-of-place tile passes (QSIM_OPT_PINGPONG) — e.g. the
+ * exchange scratch of a sharded run, idle between exchanges.  The caller keeps ownership; between qsim_flush / qsim_sync
+ * and the next gate the buffer is the caller's to use (its contents are garbage).  NULL takes it back. */
+int qsim_set_spare_buffer(qsim_state *s, void *buffer_device);
 /* Block sums / block contents for blocks that are bit-deposits instead of ranges: block w = the amplitudes at
  * deposit(w, hi_mask) | deposit(i, lo_mask), i = 0 .. 2^popcount(lo_mask) - 1 (deposit spreads the low bits of its first
  * argument over the set bits of the mask, lowest first; the masks are disjoint).  After exchanges a LOGICAL block of the

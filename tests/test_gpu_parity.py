@@ -912,3 +912,67 @@ def test_measurement_on_sharded_state(oracle, golden_dir, tmp_path, shards):
         assert m and int(m.group(1), 2) == int(m.group(2))
         hits += int(m.group(2)) in (3, 18)
     assert hits >= 25  # the two marked states carry ~99.9 % of the probability
+
+
+def test_out_of_place_passes_end_in_the_states_own_buffer(oracle, tmp_path):
+    """QSIM_OPT_PINGPONG = 2: tile passes read one buffer and write the other.  Whatever the number of passes in a flush
+    (1, 2, 3, many; fresh plans and replayed ones; with non-tile launches in between) the amplitudes match the oracle,
+    qsim_device_ptr is the same pointer before and after, and in-place runs of the same circuits agree bit for bit."""
+    n = 16
+    cases = [circuits.random_gates(n, d, 700 + d, "all") for d in (3, 40, 90, 200, 400)]
+    cases.append(circuits.random_gates(n, 300, 77, "clifford_t"))
+    with Simulator(n, fuse=3, profile=True, pingpong=2, tile_bits=10) as pp, Simulator(n, fuse=3, pingpong=0, tile_bits=10) as ip:
+        home = pp.device_ptr
+        counts = set()
+        for i, gates in enumerate(cases):
+            path = circuits.write_qasm(str(tmp_path / f"p{i}.qasm"), n, gates)
+            _, want, _, _ = oracle.run_qasm(path)
+            c = Circuit.from_file(path)
+            ip.reset(); ip.run(c)
+            ref = ip.read()
+            for rep in range(2):  # the second run replays the cached plan
+                pp.reset(); pp.reset_stats(); pp.run(c)
+                got = pp.read()
+                assert pp.device_ptr == home, (i, rep)
+                assert np.max(np.abs(got - want)) < TOL, (i, rep)
+                assert np.array_equal(got, ref), (i, rep)
+            counts.add(sum(1 for k, *_ in pp.launch_log() if k == "tile") % 2)
+        assert counts == {0, 1}  # both an even and an odd number of tile passes were exercised
+        # gates applied one flush at a time (a single pass per flush: always in place), then a state written by the caller
+        s0 = _rand_state(n, 5)
+        pp.write(s0); ip.write(s0)
+        for g in cases[1][:25]:
+            for sim in (pp, ip):
+                sim.run(Circuit.from_gates(n, [g])); sim.flush()
+        assert np.array_equal(pp.read(), ip.read()) and pp.device_ptr == home
+
+
+def test_lent_spare_buffer_with_an_external_state(oracle, tmp_path):
+    """qsim_set_spare_buffer on a state that lives in caller-owned memory (qsim_create_external — the sharded runs): the
+    result lands in the caller's buffer, the lent one is scratch; taking it back returns the state to in-place passes."""
+    import torch
+    n = 15
+    gates = circuits.random_gates(n, 350, 31, "all")
+    path = circuits.write_qasm(str(tmp_path / "x.qasm"), n, gates)
+    _, want, _, _ = oracle.run_qasm(path)
+    c = Circuit.from_file(path)
+    state = torch.zeros((1 << n, 2), dtype=torch.float64, device="cuda:0")
+    spare = torch.full((1 << n, 2), 7.0, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    with Simulator(n, fuse=3, profile=True, pingpong=2, tile_bits=10, external_ptr=state.data_ptr()) as sim:
+        sim.reset(); sim.run(c); sim.sync()
+        assert float(spare.min()) == 7.0 and float(spare.max()) == 7.0  # nothing lent yet: in place
+        sim.set_spare_buffer(spare.data_ptr())
+        for rep in range(2):
+            sim.reset(); sim.run(c); sim.sync()
+            got = state.cpu().numpy().reshape(-1).view(np.complex128)
+            assert np.max(np.abs(got - want)) < TOL, rep
+            assert sim.device_ptr == state.data_ptr()
+        assert float(spare.abs().sum()) != 7.0 * 2 * (1 << n)  # the lent buffer was written to
+        sim.set_spare_buffer(None)
+        spare.fill_(3.0); torch.cuda.synchronize()
+        sim.reset(); sim.run(c); sim.sync()
+        got = state.cpu().numpy().reshape(-1).view(np.complex128)
+        assert np.max(np.abs(got - want)) < TOL and float(spare.min()) == 3.0 and float(spare.max()) == 3.0
+        with pytest.raises(Exception):
+            sim.set_spare_buffer(state.data_ptr())

@@ -28,7 +28,7 @@ int qsim_apply_env_options(qsim_state *s) {
         {"QSIM_FUSE", QSIM_OPT_FUSE}, {"QSIM_TILE_BITS", QSIM_OPT_TILE_BITS},
         {"QSIM_TILE_LOW_BITS", QSIM_OPT_TILE_LOW_BITS}, {"QSIM_TILE_MAX_OPS", QSIM_OPT_TILE_MAX_OPS},
         {"QSIM_GRID_CAP", QSIM_OPT_GRID_CAP}, {"QSIM_PROFILE", QSIM_OPT_PROFILE},
-        {"QSIM_TILE_THREADS", QSIM_OPT_TILE_THREADS}};
+        {"QSIM_TILE_THREADS", QSIM_OPT_TILE_THREADS}, {"QSIM_PINGPONG", QSIM_OPT_PINGPONG}};
     for (size_t i = 0; i < sizeof map / sizeof map[0]; i++) {
         const char *v = getenv(map[i].env);
         if (v && *v) {

@@ -16,7 +16,7 @@
  *   QSIM_WISDOM=<path>     measured pass geometries (qsim_tune_circuit, include/qsim.h): loaded before the run if the file exists
  *   QSIM_TUNE=1            measure them for this circuit first (seconds of planning, outside the printed time) and, with
  *                          QSIM_WISDOM, save the table afterwards
- *   QSIM_DEVICE, QSIM_FUSE, QSIM_TILE_BITS, QSIM_TILE_LOW_BITS, QSIM_TILE_MAX_OPS, QSIM_GRID_CAP, QSIM_PROFILE
+ *   QSIM_DEVICE, QSIM_FUSE, QSIM_TILE_BITS, QSIM_TILE_LOW_BITS, QSIM_TILE_MAX_OPS, QSIM_GRID_CAP, QSIM_PROFILE, QSIM_PINGPONG
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -69,7 +69,7 @@ static int run_sharded(qsim_circuit *c, int shards, double t_start, long shots) 
     static const struct { const char *env; int opt; } fwd[] = {
         {"QSIM_FUSE", QSIM_OPT_FUSE}, {"QSIM_TILE_BITS", QSIM_OPT_TILE_BITS}, {"QSIM_TILE_LOW_BITS", QSIM_OPT_TILE_LOW_BITS},
         {"QSIM_TILE_MAX_OPS", QSIM_OPT_TILE_MAX_OPS}, {"QSIM_GRID_CAP", QSIM_OPT_GRID_CAP}, {"QSIM_PROFILE", QSIM_OPT_PROFILE},
-        {"QSIM_TILE_THREADS", QSIM_OPT_TILE_THREADS}};
+        {"QSIM_TILE_THREADS", QSIM_OPT_TILE_THREADS}, {"QSIM_PINGPONG", QSIM_OPT_PINGPONG}};
     for (size_t i = 0; rc == QSIM_OK && i < sizeof fwd / sizeof fwd[0]; i++)
         if ((v = getenv(fwd[i].env)) && *v) rc = qsim_cluster_set_option(cl, fwd[i].opt, atol(v));
     if (rc == QSIM_OK) rc = qsim_cluster_reset(cl);

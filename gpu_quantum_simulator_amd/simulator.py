@@ -330,7 +330,7 @@ class Cluster:
             raise _lib.QsimError(rc, (lib.qsim_cluster_error() or b"").decode())
         self.num_qubits, self.num_shards = num_q, num_shards
         names = {"fuse": _lib.OPT_FUSE, "tile_bits": _lib.OPT_TILE_BITS, "tile_low_bits": _lib.OPT_TILE_LOW_BITS,
-                 "tile_max_ops": _lib.OPT_TILE_MAX_OPS, "profile": _lib.OPT_PROFILE}
+                 "tile_max_ops": _lib.OPT_TILE_MAX_OPS, "profile": _lib.OPT_PROFILE, "pingpong": _lib.OPT_PINGPONG}
         for key in sorted(options, key=lambda k: k != "tile_low_bits"):
             self._check(lib.qsim_cluster_set_option(self._h, names[key], int(options[key])))
 

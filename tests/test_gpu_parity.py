@@ -501,16 +501,17 @@ def test_rccl_rank_comm_on_one_gpu():
     assert b"ncclSend" in subprocess.run(["nm", "-D", _lib.LIB_PATH], capture_output=True).stdout
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_virtual_shards_on_one_gpu_equal_oracle(oracle, tmp_path, world):
+@pytest.mark.parametrize("world,opts", [(2, {}), (4, {}), (8, {}), (4, {"pingpong": 2, "tile_bits": 9})])
+def test_virtual_shards_on_one_gpu_equal_oracle(oracle, tmp_path, world, opts):
     """The sharded path (planner, per-rank gates, pack kernel, block exchange) with P shards on ONE device,
-    against the oracle on the whole register."""
+    against the oracle on the whole register.  Last case: every shard's tile passes run out of place between its state
+    and its exchange scratch, which the shard lends to the engine between exchanges (HipShard)."""
     from gpu_quantum_simulator_amd.distributed import VirtualCluster
     n = 16
     gates = circuits.random_gates(n, 500, 60 + world, "all")
     path = circuits.write_qasm(str(tmp_path / "c.qasm"), n, gates)
     _, want, _, _ = oracle.run_qasm(path)
-    vc = VirtualCluster(n, world, gates)
+    vc = VirtualCluster(n, world, gates, **opts)
     try:
         vc.run()
         got = vc.gather_logical()
@@ -637,8 +638,8 @@ def test_measurement_post_path(oracle, golden_dir, tmp_path):
     assert all(l in ("MEASUREMENT: 00 (0)", "MEASUREMENT: 11 (3)") for l in lines[1:])
 
 
-@pytest.mark.parametrize("shards", [2, 4, 8, 16])
-def test_c_host_cluster_virtual_shards(oracle, tmp_path, shards):
+@pytest.mark.parametrize("shards,opts", [(2, {}), (4, {}), (8, {}), (16, {}), (4, {"pingpong": 2, "tile_bits": 9})])
+def test_c_host_cluster_virtual_shards(oracle, tmp_path, shards, opts):
     """qsim_cluster (csrc/dist.cpp): the C host's one-process sharded path, all shards on device 0.  Sixteen shards swap
     up to four qubits at once, more than the one-kernel exchange takes (eight block destinations): those exchanges go
     through the pack + copy form, in the same run as one-kernel ones."""
@@ -647,7 +648,7 @@ def test_c_host_cluster_virtual_shards(oracle, tmp_path, shards):
     path = circuits.random_circuit_file(str(tmp_path / "c.qasm"), n, 600, 80 + shards, "all")
     _, want, _, _ = oracle.run_qasm(path)
     c = Circuit.from_file(path)
-    with Cluster(n, shards, devices=[0] * shards) as cl:
+    with Cluster(n, shards, devices=[0] * shards, **opts) as cl:  # last case: out-of-place tile passes + buffer swaps at exchanges
         for _ in range(2):  # a second run must start from a clean state and map
             cl.run(c)
         assert abs(cl.norm2() - 1.0) < 1e-10

@@ -51,7 +51,7 @@ def parse_args(argv=None):
     ap.add_argument("--grid-cap", type=int, default=None)
     ap.add_argument("--tile-threads", type=int, default=None)
     ap.add_argument("--pingpong", type=int, default=None, choices=[0, 1, 2],
-                    help="QSIM_OPT_PINGPONG: tile passes out of place between two buffers (default: the library's, 1 = from 1 GiB of state)")
+                    help="QSIM_OPT_PINGPONG: tile passes out of place between two buffers (default: the library's, 1 = from 8 GiB of state)")
     ap.add_argument("--probe", type=int, default=None, metavar="Q",
                     help="single-qubit roofline probe instead of the random circuit: `depth` h gates on qubit Q, fusion off")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],

@@ -65,7 +65,7 @@ enum {
                                 * device); a queue with the same gates is replayed without scheduling or uploads.  0 = plan anew */
     QSIM_OPT_PINGPONG = 14,    /* tile passes out of place: each reads the state from one buffer and writes it to a second one, and the
                                 * two swap (an even number of times per flush: the state is back in its own buffer afterwards).  The
-                                * same bytes move ~5 % faster than in place at n = 30.  0 never, 1 (default) for states of >= 1 GiB
+                                * same bytes move ~5 % faster than in place at n = 30.  0 never, 1 (default) for states of >= 8 GiB
                                 * when the second buffer fits (allocated on first use, or lent with qsim_set_spare_buffer), 2 always */
     QSIM_OPT_DEBUG_TILE_ORDER = 12,/* measurement aid, default 0: k > 0 = every tile pass walks its high tile bits in a pseudo-random
                                   * order seeded by k (results are unchanged: the order only decides which bits lanes, waves and

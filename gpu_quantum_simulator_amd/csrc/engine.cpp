@@ -781,7 +781,7 @@ extern "C" int qsim_flush(qsim_state *s) {
     // with two buffers the most recent tile pass (and whatever followed it) is held back until the next tile pass
     // arrives: only then is it known not to be the last one, which must bring the state back to its own buffer.
     void *const home = s->amps;
-    const bool pp = spare_buffer(s) != nullptr;
+    int pp = -1; // second buffer available?  asked when the first tile pass arrives (a queue without tile passes allocates nothing)
     std::vector<Pass> held; // a tile pass, then the non-tile passes scheduled after it
     auto release = [&](bool last) {
         for (size_t i = 0; i < held.size(); i++)
@@ -790,7 +790,8 @@ extern "C" int qsim_flush(qsim_state *s) {
     };
     sched.finish([&](Pass &&p) {
         if (rc != QSIM_OK) return;
-        if (!pp) { launch(std::move(p), false); return; }
+        if (p.kclass == QSIM_K_TILE && pp < 0) pp = spare_buffer(s) != nullptr ? 1 : 0;
+        if (pp <= 0) { launch(std::move(p), false); return; }
         if (p.kclass == QSIM_K_TILE) release(false);
         if (p.kclass == QSIM_K_TILE || !held.empty()) held.push_back(std::move(p));
         else launch(std::move(p), false);

@@ -30,22 +30,26 @@ __device__ __forceinline__ uint64_t insert_zero(uint64_t t, int q) {
 // second __launch_bounds__ argument of k_tile (minimum waves per SIMD the register allocation must allow)
 #define QSIM_REAL double
 #define QSIM_AMP_SHIFT 4
+#define QSIM_COEF_PAIRS 0
 #define QSIM_TILE_MIN_WAVES(T) 1 /* fp64: B=13 x 512 threads deliberately runs at 210 VGPRs, one workgroup per CU */
 namespace f64 {
 #include "kernels_impl.inc"
 } // namespace f64
 #undef QSIM_REAL
 #undef QSIM_AMP_SHIFT
+#undef QSIM_COEF_PAIRS
 #undef QSIM_TILE_MIN_WAVES
 
 #define QSIM_REAL float
 #define QSIM_AMP_SHIFT 3
+#define QSIM_COEF_PAIRS 1 /* block coefficients arrive as (ur, ui) / (-ui, ur) pairs: v_pk_fma_f32 (kernels_impl.inc coef_t) */
 #define QSIM_TILE_MIN_WAVES(T) ((T) >= 512 ? 4 : 1) /* fp32 tiles are half the LDS bytes: always two workgroups per CU */
 namespace f32 {
 #include "kernels_impl.inc"
 } // namespace f32
 #undef QSIM_REAL
 #undef QSIM_AMP_SHIFT
+#undef QSIM_COEF_PAIRS
 #undef QSIM_TILE_MIN_WAVES
 
 // ---- precision dispatch (the engine passes the state's precision with every launch) ------------------------------

@@ -7,6 +7,7 @@ from gpu_quantum_simulator_amd import Circuit, Simulator, circuits, _lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 opts = dict(kv.split("=") for kv in sys.argv[2:])
 opts = {k: int(v) for k, v in opts.items()}
+precision = opts.pop("precision", 64)
 c = Circuit.from_gates(n, circuits.random_gates(n, 1000, 20240117 + n, "all"))
 
 
@@ -18,7 +19,7 @@ def log(sim):
     return sim.launch_log()
 
 
-with Simulator(n, fuse=3, profile=True, **opts) as sim:
+with Simulator(n, fuse=3, profile=True, precision=precision, **opts) as sim:
     full = log(sim)
     sim.set_option(_lib.OPT_DEBUG_SKIP_OPS, 1)
     mem = log(sim)

@@ -76,7 +76,7 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-KERNEL_SYMBOL = {"tile": "k_tile<12, 512>", "gate1": "k_gate1_hi<4, false>",
+KERNEL_SYMBOL = {"tile": "k_tile<12, 512, false>", "gate1": "k_gate1_hi<4, false>",
                  "gate1_lo": "k_gate1_lo<4, false>", "gate2": "k_gate2_hh<2, false>"}  # inside namespace qsim::f64
 
 
@@ -275,6 +275,24 @@ class Bench:
         stats = sim.stats()
         norm2 = sim.norm2()
 
+        # For the record: the same steps with every pass sweeping the whole register (QSIM_OPT_SPARSE_START = 0).  By default
+        # the first passes after a reset only visit the tiles inside the state's support — same
+        # amplitudes, fewer bytes; `value` is the default path, this is what it would be without that.
+        full_sweeps = None
+        if dist is None and probe_q is None and fuse >= 3:
+            from gpu_quantum_simulator_amd import _lib as _qlib
+            sim.set_option(_qlib.OPT_SPARSE_START, 0)
+            run_step()
+            self.fence(sim)
+            k = max(1, min(steps, 3))
+            t1 = time.perf_counter()
+            for _ in range(k):
+                run_step()
+            self.fence(sim)
+            dt = time.perf_counter() - t1
+            sim.set_option(_qlib.OPT_SPARSE_START, 1)
+            full_sweeps = {"ms_per_step": 1e3 * dt / k, "value": depth * k / dt, "steps": k}
+
         # north_star target "single-qubit gate apply at n=30": a short dense-1q probe on the same (now dense) state
         probe = None
         if with_1q_probe and dist is None and probe_q is None and n >= 8:
@@ -294,7 +312,7 @@ class Bench:
                 probe[f"q{q}"] = {"kernel": name, "achieved": gbs, "frac": gbs / HBM_PEAK_GBPS, "avg_launch_ms": k[name]["ms"] / 6}
 
         res = {"workload": workload, "n": n, "gates": gates, "elapsed": elapsed, "steps": steps, "stats": stats,
-               "norm2": norm2, "probe": probe, "fuse": fuse, "tuning": tuning}
+               "norm2": norm2, "probe": probe, "fuse": fuse, "tuning": tuning, "full_sweeps": full_sweeps}
         if dist is not None:
             xs, xb = sim.exchange_seconds / steps, sim.exchange_bytes / steps
             res["exchange"] = {"per_step": sim.plan.exchanges,
@@ -385,6 +403,13 @@ def main():
             "roofline_1q_probe": head["probe"],
             "geometry_planning": head["tuning"],
         }
+        if head.get("full_sweeps"):
+            tile = stats["kernels"].get("tile")
+            swept = (tile["bytes"] / (tile["launches"] * 2.0 * (16 if args.precision == 64 else 8) * (1 << n))) if tile and tile["launches"] else None
+            out["sparse_start"] = {"note": "after a reset, tile passes visit only the tiles inside the state's support (the first pass "
+                                           "writes one tile, the full sweeps start once every qubit has been inside a tile); "
+                                           "same amplitudes, fewer bytes.  with_full_sweeps: the same steps with the option off",
+                                   "tile_bytes_vs_full_sweeps": swept, "with_full_sweeps": head["full_sweeps"]}
         if "exchange" in head:
             out["exchange"] = head["exchange"]
         cpu = not args.no_cpu_baseline and args.gpus == 1 and b.dist is None
@@ -400,7 +425,7 @@ def main():
                        "value": args.depth * r["steps"] / r["elapsed"], "unit": "gate-applies/s",
                        "ms_per_step": 1e3 * r["elapsed"] / r["steps"], "steps": r["steps"],
                        "launches_per_step": r["stats"]["launches"] / r["steps"], "norm2": r["norm2"],
-                       "geometry_planning": r["tuning"],
+                       "geometry_planning": r["tuning"], "with_full_sweeps": r.get("full_sweeps"),
                        "roofline": None if rf is None else {k: rf[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms")}}
                 if (16 << r["n"]) <= (256 << 20) and row["roofline"]:
                     row["roofline"]["note"] = "the state fits the 256 MiB Infinity Cache: passes run from cache, the HBM roofline does not bound them"

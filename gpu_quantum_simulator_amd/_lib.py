@@ -19,6 +19,7 @@ OPT_DEBUG_SKIP_MEM = 11
 OPT_DEBUG_TILE_ORDER = 12
 OPT_PLAN_CACHE = 13
 OPT_PINGPONG = 14
+OPT_SPARSE_START = 15
 K_NAMES = ("init", "gate1", "gate1_lo", "phase", "cx", "gate2", "tile", "pack")
 K_COUNT = len(K_NAMES)
 

@@ -107,6 +107,15 @@ struct qsim_state {
     std::vector<QueuedGate> queue;
     double zero_ket_amp = 1.0;     // amplitude at index 0 of the pending basis state (0: a shard that does not hold index 0)
     bool zero_ket_pending = false; // |0...0> requested but not written yet (folded into the first tile pass if possible)
+    // After a reset the state is zero wherever an index bit outside `support` is set, and stays so until a pass mixes that
+    // qubit in: the first tile pass writes ONE tile (every other tile is zero), the second 2^(tile qubits new to it)
+    // tiles, and so on until the support is the whole register — typically the third pass of a random circuit.  While
+    // `partial` is set, memory outside the support has never been written (it is zero by definition): tile passes visit
+    // only tiles inside it and stage the rest of a tile in as zeros (launch_tile zero_mask); anything else that looks at
+    // the buffer (other kernels, reads, exchanges) first gets the zeros written (materialize_zero_ket).
+    bool partial = false;
+    uint64_t support = 0; // qubits some tile pass has had inside its tile since the reset
+    int sparse_start = 1; // QSIM_OPT_SPARSE_START
     // op ring for tile passes
     TileOp *d_ops = nullptr, *h_ops = nullptr;
     size_t ops_cap = 0, ops_used = 0;
@@ -244,6 +253,9 @@ extern "C" int qsim_set_option(qsim_state *s, int option, long value) {
     case QSIM_OPT_PLAN_CACHE:
         s->plan_cache = value != 0;
         break;
+    case QSIM_OPT_SPARSE_START:
+        s->sparse_start = value != 0;
+        break;
     case QSIM_OPT_PINGPONG:
         if (value < 0 || value > 2) return fail(QSIM_ERR_ARG, "pingpong must be 0 (never), 1 (auto) or 2 (always)");
         s->pingpong = (int)value;
@@ -277,6 +289,7 @@ extern "C" long qsim_get_option(const qsim_state *s, int option) {
     case QSIM_OPT_DEBUG_TILE_ORDER: return s->debug_tile_order;
     case QSIM_OPT_PLAN_CACHE: return s->plan_cache;
     case QSIM_OPT_PINGPONG: return s->pingpong;
+    case QSIM_OPT_SPARSE_START: return s->sparse_start;
     default: return -1;
     }
 }
@@ -337,17 +350,29 @@ static void account(qsim_state *s, int kclass, double bytes) {
     s->stats.k_bytes[kclass] += bytes;
 }
 
-// Writes the pending |0...0> with the init kernel (when the next operation cannot generate it itself).
+// Writes the pending |0...0> with the init kernel (when the next operation cannot generate it itself), or the zeros of a
+// state that has only been written inside its support so far.
 static int materialize_zero_ket(qsim_state *s) {
-    if (!s->zero_ket_pending) return QSIM_OK;
+    if (!s->zero_ket_pending && !s->partial) return QSIM_OK;
     HIP_TRY(hipSetDevice(s->device)); // a cluster drives several devices from one thread
-    s->zero_ket_pending = false;
     LaunchCfg cfg{s->stream, s->grid_cap};
-    {
-        LaunchScope scope(s, QSIM_K_INIT);
-        HIP_TRY(launch_init(cfg, s->amps, s->f32, s->n, s->zero_ket_amp));
+    const double state_bytes = (double)s->amp_bytes() * (double)(1ULL << s->n);
+    if (s->zero_ket_pending) {
+        s->zero_ket_pending = false;
+        {
+            LaunchScope scope(s, QSIM_K_INIT);
+            HIP_TRY(launch_init(cfg, s->amps, s->f32, s->n, s->zero_ket_amp));
+        }
+        account(s, QSIM_K_INIT, state_bytes);
+    } else {
+        const uint64_t nmask = s->n >= 64 ? ~0ULL : ((1ULL << s->n) - 1ULL);
+        {
+            LaunchScope scope(s, QSIM_K_INIT);
+            HIP_TRY(launch_zero_outside(cfg, s->amps, s->f32, s->n, nmask & ~s->support));
+        }
+        account(s, QSIM_K_INIT, state_bytes * (1.0 - 1.0 / (double)(1ULL << __builtin_popcountll(nmask & ~s->support))));
     }
-    account(s, QSIM_K_INIT, (double)s->amp_bytes() * (double)(1ULL << s->n));
+    s->partial = false;
     return QSIM_OK;
 }
 
@@ -362,6 +387,8 @@ extern "C" int qsim_reset_shard(qsim_state *s, int holds_index0) {
     // |0...0> is not written here: if the first pass after the reset is a tile pass it generates the state in LDS
     // (one write of the state instead of write + read + write); anything else materialises it first.
     s->zero_ket_pending = true;
+    s->partial = false;
+    s->support = 0;
     return QSIM_OK;
 }
 
@@ -602,7 +629,7 @@ static void *spare_buffer(qsim_state *s) {
 
 // Launches a tile pass whose TileOps are already on the device (no statistics, no profiling events).  oop: write the
 // state to the spare buffer and make that the state (the caller checked spare_buffer()).
-static int launch_tile_prepared(qsim_state *s, const TileGeom &geom, const TileOp *d, int need, bool from_zero_ket, bool oop = false) {
+static int launch_tile_prepared(qsim_state *s, const TileGeom &geom, const TileOp *d, int need, bool from_zero_ket, bool oop = false, uint64_t zero_mask = 0) {
     LaunchCfg cfg{s->stream, s->grid_cap};
     const int threads = s->tile_threads; // 0: default for the tile size
     void *out = oop ? s->spare : s->amps;
@@ -610,9 +637,9 @@ static int launch_tile_prepared(qsim_state *s, const TileGeom &geom, const TileO
     if (s->debug_skip_ops) {
         TileGeom bare = geom;
         bare.n_scale = 0;
-        e = launch_tile(cfg, s->amps, out, s->f32, bare, d, 0, threads, from_zero_ket, s->zero_ket_amp);
+        e = launch_tile(cfg, s->amps, out, s->f32, bare, d, 0, threads, from_zero_ket, s->zero_ket_amp, false, zero_mask);
     } else {
-        e = launch_tile(cfg, s->amps, out, s->f32, geom, d, need, threads, from_zero_ket, s->zero_ket_amp, s->debug_skip_mem != 0);
+        e = launch_tile(cfg, s->amps, out, s->f32, geom, d, need, threads, from_zero_ket, s->zero_ket_amp, s->debug_skip_mem != 0, zero_mask);
     }
     if (e != hipSuccess) return fail(QSIM_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
     if (oop) std::swap(s->amps, s->spare);
@@ -621,7 +648,7 @@ static int launch_tile_prepared(qsim_state *s, const TileGeom &geom, const TileO
 
 // Prepares the blocks of a tile pass for the given bit order in the pinned ring, uploads and launches them; `capture`
 // (optional) receives a copy of the prepared TileOps for the plan cache.
-static int launch_tile_pass(qsim_state *s, const Pass &p, const TileGeom &geom, bool from_zero_ket, std::vector<TileOp> *capture = nullptr, bool oop = false) {
+static int launch_tile_pass(qsim_state *s, const Pass &p, const TileGeom &geom, bool from_zero_ket, std::vector<TileOp> *capture = nullptr, bool oop = false, uint64_t zero_mask = 0) {
     const size_t need = p.blocks.size();
     if (need > s->ops_cap) return fail(QSIM_ERR_ARG, "tile pass with %zu ops exceeds the op buffer", need);
     if (s->ops_used + need > s->ops_cap) { // ring is full: wait until earlier passes have read their ops
@@ -644,7 +671,7 @@ static int launch_tile_pass(qsim_state *s, const Pass &p, const TileGeom &geom, 
     TileOp *d = s->d_ops + s->ops_used;
     HIP_TRY(hipMemcpyAsync(d, h, need * sizeof(TileOp), hipMemcpyHostToDevice, s->stream));
     s->ops_used += need;
-    return launch_tile_prepared(s, geom, d, (int)need, from_zero_ket, oop);
+    return launch_tile_prepared(s, geom, d, (int)need, from_zero_ket, oop, zero_mask);
 }
 
 // cached_geom / cached_ops: replay of a cached plan (the tile pass's order and device-resident TileOps);
@@ -652,7 +679,7 @@ static int launch_tile_pass(qsim_state *s, const Pass &p, const TileGeom &geom, 
 static int launch_pass(qsim_state *s, const Pass &p, const TileGeom *cached_geom = nullptr, const TileOp *cached_ops = nullptr,
                        std::vector<TileOp> *capture = nullptr, TileGeom *geom_out = nullptr, bool oop = false) {
     const bool from_zero_ket = s->zero_ket_pending && p.kclass == QSIM_K_TILE;
-    if (s->zero_ket_pending && !from_zero_ket) {
+    if ((s->zero_ket_pending || s->partial) && p.kclass != QSIM_K_TILE) { // only tile passes work on a partially written state
         const int rc = materialize_zero_ket(s);
         if (rc) return rc;
     }
@@ -660,6 +687,7 @@ static int launch_pass(qsim_state *s, const Pass &p, const TileGeom *cached_geom
     LaunchCfg cfg{s->stream, s->grid_cap};
     const FusedOp &op = p.ops[0];
     hipError_t e = hipSuccess;
+    double visited = 1.0; // fraction of the tiles a tile pass works on
     switch (p.kclass) {
     case QSIM_K_GATE1:
     case QSIM_K_GATE1_LO: {
@@ -696,17 +724,28 @@ static int launch_pass(qsim_state *s, const Pass &p, const TileGeom *cached_geom
         if (geom_out) *geom_out = geom;
         uint64_t hm = 0, oc = 0;
         for (int j = 0; j < geom.n_high; j++) { hm |= 1ULL << geom.high[j]; oc |= (uint64_t)geom.high[j] << (5 * j); }
+        // the part of the register this pass has to visit (qsim_state::support)
+        const uint64_t nmask = s->n >= 64 ? ~0ULL : ((1ULL << s->n) - 1ULL);
+        const uint64_t tmask = hm | ((1ULL << geom.low_bits) - 1ULL);
+        uint64_t zero_mask = 0;
+        if (s->sparse_start && from_zero_ket) zero_mask = nmask;
+        else if (s->partial) zero_mask = nmask & ~s->support;
+        visited = 1.0 / (double)(1ULL << __builtin_popcountll(zero_mask & ~tmask));
         LaunchScope scope(s, p.kclass, (int)p.blocks.size(), hm, oc);
-        const int rc = cached_ops ? launch_tile_prepared(s, geom, cached_ops, (int)p.blocks.size(), from_zero_ket, oop)
-                                  : launch_tile_pass(s, p, geom, from_zero_ket, capture, oop);
+        const int rc = cached_ops ? launch_tile_prepared(s, geom, cached_ops, (int)p.blocks.size(), from_zero_ket, oop, zero_mask)
+                                  : launch_tile_pass(s, p, geom, from_zero_ket, capture, oop, zero_mask);
         if (rc) return rc;
+        if (zero_mask) {
+            s->support = (from_zero_ket ? 0 : s->support) | tmask;
+            s->partial = (s->support & nmask) != nmask;
+        }
         break;
     }
     default: return fail(QSIM_ERR_ARG, "internal: unknown kernel class %d", p.kclass);
     }
     if (e != hipSuccess) return fail(QSIM_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
     const double scale = s->f32 ? 0.5 : 1.0; // the scheduler prices passes for 16-byte amplitudes
-    account(s, p.kclass, scale * (from_zero_ket ? p.bytes / 2 : p.bytes)); // a generating pass only writes
+    account(s, p.kclass, scale * visited * (from_zero_ket ? p.bytes / 2 : p.bytes)); // a generating pass only writes
     return QSIM_OK;
 }
 

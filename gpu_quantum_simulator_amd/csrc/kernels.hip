@@ -55,6 +55,7 @@ namespace f32 {
 // ---- precision dispatch (the engine passes the state's precision with every launch) ------------------------------
 #define QSIM_DISPATCH(CALL) (f32 ? f32::CALL : f64::CALL)
 hipError_t launch_init(const LaunchCfg &cfg, void *v, bool f32, int n, double amp0) { return QSIM_DISPATCH(launch_init(cfg, v, n, amp0)); }
+hipError_t launch_zero_outside(const LaunchCfg &cfg, void *v, bool f32, int n, uint64_t zero_mask) { return QSIM_DISPATCH(launch_zero_outside(cfg, v, n, zero_mask)); }
 hipError_t launch_gate1(const LaunchCfg &cfg, void *v, bool f32, int n, int q, const M2 &U) { return QSIM_DISPATCH(launch_gate1(cfg, v, n, q, U)); }
 hipError_t launch_phase(const LaunchCfg &cfg, void *v, bool f32, int n, int q, double lr, double li) { return QSIM_DISPATCH(launch_phase(cfg, v, n, q, lr, li)); }
 hipError_t launch_diag1_full(const LaunchCfg &cfg, void *v, bool f32, int n, int q, double d0r, double d0i, double d1r, double d1i) {
@@ -63,8 +64,8 @@ hipError_t launch_diag1_full(const LaunchCfg &cfg, void *v, bool f32, int n, int
 hipError_t launch_cx(const LaunchCfg &cfg, void *v, bool f32, int n, int control, int target) { return QSIM_DISPATCH(launch_cx(cfg, v, n, control, target)); }
 hipError_t launch_gate2(const LaunchCfg &cfg, void *v, bool f32, int n, int q_hi, int q_lo, const M4 &U) { return QSIM_DISPATCH(launch_gate2(cfg, v, n, q_hi, q_lo, U)); }
 hipError_t launch_tile(const LaunchCfg &cfg, void *v, void *vout, bool f32, const TileGeom &g, const TileOp *d_ops, int n_ops, int threads, bool from_zero_ket,
-                       double amp0, bool nomem) {
-    return QSIM_DISPATCH(launch_tile(cfg, v, vout, g, d_ops, n_ops, threads, from_zero_ket, amp0, nomem));
+                       double amp0, bool nomem, uint64_t zero_mask) {
+    return QSIM_DISPATCH(launch_tile(cfg, v, vout, g, d_ops, n_ops, threads, from_zero_ket, amp0, nomem, zero_mask));
 }
 hipError_t launch_norm2(const LaunchCfg &cfg, const void *v, bool f32, int n, double *d_out) { return QSIM_DISPATCH(launch_norm2(cfg, v, n, d_out)); }
 hipError_t launch_block_prob(const LaunchCfg &cfg, const void *v, bool f32, int n, int block_bits, double *d_out) {

@@ -91,9 +91,13 @@ hipError_t launch_diag1_full(const LaunchCfg &cfg, void *v, bool f32, int n, int
 hipError_t launch_cx(const LaunchCfg &cfg, void *v, bool f32, int n, int control, int target);
 hipError_t launch_gate2(const LaunchCfg &cfg, void *v, bool f32, int n, int q_hi, int q_lo, const M4 &U);
 // from_zero_ket: the state is a not-yet-written basis state; the pass generates it in LDS instead of loading it
+// zero_mask: index bits the state is known to be |0> in — tiles with such a bit in their base index are skipped, slots
+// with one inside a tile are staged in as zero (their memory may never have been written)
 // vout: where the pass writes the state — v itself (in place) or a second buffer of the same size
 hipError_t launch_tile(const LaunchCfg &cfg, void *v, void *vout, bool f32, const TileGeom &g, const TileOp *d_ops, int n_ops, int threads,
-                       bool from_zero_ket, double amp0, bool nomem = false);
+                       bool from_zero_ket, double amp0, bool nomem = false, uint64_t zero_mask = 0);
+// zeroes the amplitudes whose index has a bit of zero_mask set (the part of a state the tile passes have not written yet)
+hipError_t launch_zero_outside(const LaunchCfg &cfg, void *v, bool f32, int n, uint64_t zero_mask);
 hipError_t launch_norm2(const LaunchCfg &cfg, const void *v, bool f32, int n, double *d_out /* zeroed */);
 // d_out[b] = sum of |a|^2 over amplitudes [b << block_bits, (b+1) << block_bits), fixed summation order
 hipError_t launch_block_prob(const LaunchCfg &cfg, const void *v, bool f32, int n, int block_bits, double *d_out);

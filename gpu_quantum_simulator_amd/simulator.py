@@ -163,7 +163,7 @@ class Simulator:
                  "grid_cap": _lib.OPT_GRID_CAP, "tile_threads": _lib.OPT_TILE_THREADS,
                  "tile_pad_from": _lib.OPT_TILE_PAD_FROM, "debug_skip_ops": _lib.OPT_DEBUG_SKIP_OPS,
                  "debug_skip_mem": _lib.OPT_DEBUG_SKIP_MEM, "debug_tile_order": _lib.OPT_DEBUG_TILE_ORDER, "plan_cache": _lib.OPT_PLAN_CACHE,
-                 "pingpong": _lib.OPT_PINGPONG}
+                 "pingpong": _lib.OPT_PINGPONG, "sparse_start": _lib.OPT_SPARSE_START}
         # tile_low_bits first when shrinking, tile_bits first when growing: keep every intermediate valid
         for key in sorted(options, key=lambda k: k != "tile_low_bits"):
             self.set_option(names[key], options[key])

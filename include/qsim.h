@@ -67,6 +67,10 @@ enum {
                                 * two swap (an even number of times per flush: the state is back in its own buffer afterwards).  The
                                 * same bytes move ~5 % faster than in place at n = 30.  0 never, 1 (default) for states of >= 8 GiB
                                 * when the second buffer fits (allocated on first use, or lent with qsim_set_spare_buffer), 2 always */
+    QSIM_OPT_SPARSE_START = 15,/* default 1: after a reset the state is zero wherever a qubit no pass has mixed yet is 1, and the tile
+                                * passes only visit the rest: the first pass of a circuit writes one tile, the second a few hundred,
+                                * the full sweeps start when every qubit has been inside a tile (memory outside that support is
+                                * written as zeros the moment anything else looks at the buffer).  0 = every pass sweeps the register */
     QSIM_OPT_DEBUG_TILE_ORDER = 12,/* measurement aid, default 0: k > 0 = every tile pass walks its high tile bits in a pseudo-random
                                   * order seeded by k (results are unchanged: the order only decides which bits lanes, waves and
                                   * registers walk) */

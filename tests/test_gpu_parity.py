@@ -977,3 +977,49 @@ def test_lent_spare_buffer_with_an_external_state(oracle, tmp_path):
         assert np.max(np.abs(got - want)) < TOL and float(spare.min()) == 3.0 and float(spare.max()) == 3.0
         with pytest.raises(Exception):
             sim.set_spare_buffer(state.data_ptr())
+
+
+def test_sparse_start_visits_only_the_support(oracle, tmp_path):
+    """QSIM_OPT_SPARSE_START: after a reset the tile passes only visit tiles inside the state's support and treat memory
+    outside it as zero without ever having written it.  Checked where that can go wrong: stale amplitudes of an earlier,
+    dense run in both buffers; a circuit that leaves most qubits untouched (the zeros are only written when the state is
+    read); a single-kernel gate and a caller's write in the middle of the sparse phase; bit-exact agreement with plain
+    full sweeps; and the launch log shows the first passes moving a fraction of the bytes."""
+    n = 18
+    dense = Circuit.from_gates(n, circuits.random_gates(n, 400, 5, "all"))
+    few = [g for g in circuits.random_gates(7, 120, 9, "all")]           # touches qubits 0..6 only
+    path = circuits.write_qasm(str(tmp_path / "few.qasm"), n, few)
+    _, want_few, _, _ = oracle.run_qasm(path)
+    c_few = Circuit.from_file(path)
+    gates = circuits.random_gates(n, 500, 21, "all")
+    path2 = circuits.write_qasm(str(tmp_path / "r.qasm"), n, gates)
+    _, want, _, _ = oracle.run_qasm(path2)
+    c = Circuit.from_file(path2)
+    for pp in (0, 2):
+        with Simulator(n, fuse=3, profile=True, pingpong=pp, tile_bits=10) as sim, \
+                Simulator(n, fuse=3, pingpong=pp, tile_bits=10, sparse_start=0) as full:
+            sim.run(dense); sim.sync()                                   # leaves dense garbage behind
+            sim.reset(); sim.run(c_few)
+            got = sim.read()
+            assert np.max(np.abs(got - want_few)) < TOL and not got[128:].any()
+            sim.reset(); sim.reset_stats(); sim.run(c)
+            got = sim.read()
+            full.run(c)
+            assert np.max(np.abs(got - want)) < TOL and np.array_equal(got, full.read())
+            st = sim.stats()
+            tile = st["kernels"]["tile"]
+            assert tile["bytes"] < 0.95 * tile["launches"] * 32 * (1 << n)  # the first passes did not sweep the register
+            # a dense single-qubit kernel (its own launch at fuse 0) and a write in the middle of the sparse phase
+            sim.set_option(_lib.OPT_FUSE, 3)
+            sim.reset(); sim.run(Circuit.from_gates(n, gates[:40])); sim.flush()
+            sim.set_option(_lib.OPT_FUSE, 0)
+            sim.run(Circuit.from_gates(n, gates[40:45])); sim.flush()
+            sim.set_option(_lib.OPT_FUSE, 3)
+            sim.run(Circuit.from_gates(n, gates[45:])); sim.flush()
+            assert np.max(np.abs(sim.read() - want)) < TOL
+            s0 = _rand_state(n, 77)
+            sim.reset(); sim.run(Circuit.from_gates(n, gates[:30])); sim.flush()
+            sim.write(s0)
+            sim.run(Circuit.from_gates(n, gates[:60]))
+            full.write(s0); full.run(Circuit.from_gates(n, gates[:60]))
+            assert np.array_equal(sim.read(), full.read())

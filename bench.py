@@ -72,6 +72,8 @@ def parse_args(argv=None):
     ap.add_argument("--tune-candidates", type=int, default=48)
     ap.add_argument("--tune-ms", type=float, default=8000.0, help="wall-time budget of the planning step per register size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-sweeps", action="store_true",
+                    help="skip the extra steps with QSIM_OPT_SPARSE_START off (profile runs: every launch then is one of the timed kind)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args(argv)
 
@@ -279,7 +281,7 @@ class Bench:
         # the first passes after a reset only visit the tiles inside the state's support — same
         # amplitudes, fewer bytes; `value` is the default path, this is what it would be without that.
         full_sweeps = None
-        if dist is None and probe_q is None and fuse >= 3:
+        if dist is None and probe_q is None and fuse >= 3 and not args.no_full_sweeps:
             from gpu_quantum_simulator_amd import _lib as _qlib
             sim.set_option(_qlib.OPT_SPARSE_START, 0)
             run_step()

@@ -1,5 +1,6 @@
 """One-off randomised parity stress (not part of the test suite): many seeded circuits x engine options (tile shape, ops
-per pass, shuffled tile-bit orders, plan cache on/off, fp32, virtual-shard clusters) against the oracle."""
+per pass, shuffled tile-bit orders, plan cache on/off, out-of-place passes, sparse start, fp32, virtual-shard clusters)
+against the oracle."""
 import os
 import sys
 import tempfile
@@ -22,7 +23,7 @@ with tempfile.TemporaryDirectory() as d:
         tile_bits = int(rng.integers(8, 14))
         opts = {"tile_bits": tile_bits, "tile_low_bits": int(rng.integers(max(2, tile_bits - 10), min(6, tile_bits - 2) + 1)),
                 "tile_max_ops": int(rng.integers(1, 40)), "debug_tile_order": int(rng.integers(0, 6)),
-                "plan_cache": int(rng.integers(0, 2))}
+                "plan_cache": int(rng.integers(0, 2)), "pingpong": int(rng.choice([0, 2])), "sparse_start": int(rng.integers(0, 2))}
         kind = rng.random()
         if kind < 0.7:
             with Simulator(n, fuse=3, **opts) as sim:
@@ -41,7 +42,7 @@ with tempfile.TemporaryDirectory() as d:
             P = int(rng.choice([2, 4, 8]))
             if n - int(np.log2(P)) < 2:
                 continue
-            with Cluster(n, P, devices=[0] * P) as cl:
+            with Cluster(n, P, devices=[0] * P, pingpong=opts["pingpong"], tile_bits=min(opts["tile_bits"], 12)) as cl:
                 cl.run(c)
                 err = float(np.max(np.abs(cl.read() - want)))
                 worst["cluster"] = max(worst["cluster"], err)

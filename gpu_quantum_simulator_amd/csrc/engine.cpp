@@ -429,9 +429,11 @@ extern "C" int qsim_apply_2q(qsim_state *s, const double *U, int q_hi, int q_lo)
 }
 
 // ---- scheduling + launch -------------------------------------------------------------------------------
-static SchedConfig sched_config(int n, int fuse, int tile_bits, int tile_low_bits, int tile_max_ops, int pad_from = 10, bool f32 = false) {
+static SchedConfig sched_config(int n, int fuse, int tile_bits, int tile_low_bits, int tile_max_ops, int pad_from = 10, bool f32 = false,
+                                uint64_t initial_support = 0) {
     SchedConfig c;
     c.pad_from = pad_from;
+    c.initial_support = initial_support; // 0: the run starts from a reset (what the planning entry points assume)
     c.n = n; c.fuse = fuse; c.tile_bits = tile_bits; c.tile_low_bits = tile_low_bits; c.tile_max_ops = tile_max_ops;
     // The pass-set local search (SchedConfig::local_iters with one pass of lookahead) costs ~1.5 ms of host time per
     // pass.  Passes are launched as they are produced, so the search is free once a pass runs longer than that on the
@@ -749,6 +751,13 @@ static int launch_pass(qsim_state *s, const Pass &p, const TileGeom *cached_geom
     return QSIM_OK;
 }
 
+// Qubits that may be 1 somewhere in the state when the next pass runs (SchedConfig::initial_support).
+static uint64_t current_support(const qsim_state *s) {
+    if (!s->sparse_start) return ~0ULL;
+    if (s->zero_ket_pending) return 0;
+    return s->partial ? s->support : ~0ULL;
+}
+
 static uint64_t queue_key(const qsim_state *s) {
     uint64_t h = 0xcbf29ce484222325ULL; // FNV-1a over the options that shape a plan and over every queued gate
     auto mix = [&](const void *p, size_t n) {
@@ -757,6 +766,8 @@ static uint64_t queue_key(const qsim_state *s) {
     };
     const int opts[8] = {s->n, s->f32 ? 1 : 0, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, (int)s->queue.size()};
     mix(opts, sizeof opts);
+    const uint64_t sup = current_support(s); // the schedule depends on where the state is known to be zero
+    mix(&sup, sizeof sup);
     for (const QueuedGate &g : s->queue) {
         const int hd[3] = {g.kind, g.q0, g.q1};
         mix(hd, sizeof hd);
@@ -798,7 +809,7 @@ extern "C" int qsim_flush(qsim_state *s) {
             return QSIM_OK;
         }
     }
-    Scheduler sched(sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32));
+    Scheduler sched(sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32, current_support(s)));
     for (const QueuedGate &g : s->queue) {
         if (g.kind == QSIM_GATE_U1) sched.add_1q(g.m, g.q0);
         else if (g.kind == QSIM_GATE_CX) sched.add_cx(g.q0, g.q1);
@@ -1228,7 +1239,8 @@ extern "C" int qsim_tune_circuit(qsim_state *s, const qsim_circuit *c, int max_c
     int rc = qsim_sync(s);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(s->device));
-    Scheduler sched(sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32));
+    Scheduler sched(sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32,
+                                 s->sparse_start ? 0 : ~0ULL)); // the run that follows starts from the reset this call ends with
     feed(sched, c);
     std::vector<Pass> passes;
     sched.finish(passes);

@@ -108,6 +108,7 @@ Scheduler::Scheduler(const SchedConfig &cfg) : cfg_(cfg), open_(cfg.n > 0 ? cfg.
     if (const char *v = getenv("QSIM_SCHED_OBJ")) cfg_.objective = atoi(v);
     if (const char *v = getenv("QSIM_SCHED_MERGE")) cfg_.merge = atoi(v);
     if (const char *v = getenv("QSIM_SCHED_MERGEQ")) cfg_.merge_qubits = atoi(v);
+    if (const char *v = getenv("QSIM_SCHED_CHEAP")) cfg_.cheap_margin = atof(v);
 }
 
 void Scheduler::close(int idx) {
@@ -446,7 +447,7 @@ void Scheduler::single_op_pass(const FusedOp &op, const PassSink &sink) const {
     }
 }
 
-void Scheduler::tile_pass(const std::vector<FusedOp> &ops, uint64_t hset, const PassSink &sink) const {
+uint64_t Scheduler::tile_pass(const std::vector<FusedOp> &ops, uint64_t hset, const PassSink &sink, uint64_t prefer) const {
     const int B = std::min(cfg_.tile_bits, cfg_.n);
     const int L = std::min(cfg_.tile_low_bits, B);
     const uint64_t lowmask = (1ULL << L) - 1ULL;
@@ -464,7 +465,7 @@ void Scheduler::tile_pass(const std::vector<FusedOp> &ops, uint64_t hset, const 
         while (__builtin_popcountll(high) < B - L) {
             int best = -1;
             for (int b = L; b < cfg_.n; b++)
-                if (uses[b] > 0 && (best < 0 || uses[b] > uses[best])) best = b;
+                if (uses[b] > 0 && (prefer >> b & 1ULL) && (best < 0 || uses[b] > uses[best])) best = b;
             if (best < 0) break;
             high |= 1ULL << best;
             uses[best] = 0;
@@ -475,8 +476,11 @@ void Scheduler::tile_pass(const std::vector<FusedOp> &ops, uint64_t hset, const 
     // bits (longest contiguous runs) costs up to 8.6 ms per pass against 6.8 ms when bits 10.. are used; 10 had the
     // best worst case over the geometries tried (<= 6.9 ms)
     const int start = cfg_.pad_from >= L && cfg_.pad_from < cfg_.n ? cfg_.pad_from : L;
-    for (int b = start; b < cfg_.n && __builtin_popcountll(high) < B - L; b++) high |= 1ULL << b;
-    for (int b = L; b < start && __builtin_popcountll(high) < B - L; b++) high |= 1ULL << b;
+    for (int round = 0; round < 2; round++) { // bits of `prefer` first: padding must not grow a partial state's support
+        const uint64_t ok = round == 0 ? prefer : ~0ULL;
+        for (int b = start; b < cfg_.n && __builtin_popcountll(high) < B - L; b++) if (ok >> b & 1ULL) high |= 1ULL << b;
+        for (int b = L; b < start && __builtin_popcountll(high) < B - L; b++) if (ok >> b & 1ULL) high |= 1ULL << b;
+    }
     p.geom.tile_bits = L + __builtin_popcountll(high);
     p.geom.low_bits = L;
     p.geom.n = cfg_.n;
@@ -511,8 +515,10 @@ void Scheduler::tile_pass(const std::vector<FusedOp> &ops, uint64_t hset, const 
     p.geom.n_scale = (int)scalars.size();
     p.blocks = std::move(scalars);
     p.blocks.insert(p.blocks.end(), blocks.begin(), blocks.end());
-    if (p.blocks.empty()) return;
+    const uint64_t tmask = lowmask | high;
+    if (p.blocks.empty()) return 0; // every block was the identity: nothing is launched, nothing changes
     sink(std::move(p));
+    return tmask;
 }
 
 void Scheduler::build_passes(const PassSink &sink) {
@@ -647,10 +653,48 @@ void Scheduler::build_passes(const PassSink &sink) {
     };
 
     std::vector<Cand> cands;
+    // The state's support as the engine will track it (SchedConfig::initial_support): tile passes add their tile's qubits,
+    // anything else makes the engine write the zeros out (dense from then on).
+    uint64_t support = cfg_.initial_support & all;
+    auto note_tile = [&](uint64_t tmask) { if (tmask) support |= tmask; };
+    std::vector<long> picks0;
     while (first < m) {
         if (done[first]) { first++; continue; }
         group.clear();
         uint64_t hset = 0;
+        if (support != all && support != 0 && cfg_.cheap_margin > 0) {
+            // A pass that stays inside the support visits 2^(|support| - n) of the register: greedy, cheapest cluster first
+            const size_t end0 = std::min(m, first + (size_t)cfg_.window);
+            std::vector<char> work0 = done;
+            uint64_t h0 = 0;
+            picks0.clear();
+            while ((int)picks0.size() < cfg_.tile_max_ops) {
+                long pick = -1;
+                int bestneed = 1 << 30;
+                uint64_t blocked = 0;
+                const int used = __builtin_popcountll(h0);
+                for (size_t i = first; i < end0; i++) {
+                    if (work0[i]) continue;
+                    if (!(qm[i] & blocked) && !(must[i] & ~lowmask & ~support)) {
+                        const int need = __builtin_popcountll(must[i] & ~lowmask & ~h0);
+                        if (used + need <= kmax && need < bestneed) { bestneed = need; pick = (long)i; if (need == 0) break; }
+                    }
+                    blocked |= qm[i];
+                    if (blocked == all) break;
+                }
+                if (pick < 0) break;
+                work0[(size_t)pick] = 1;
+                h0 |= must[(size_t)pick] & ~lowmask;
+                picks0.push_back(pick);
+            }
+            const double share = 1.0 / (double)(1ULL << (cfg_.n - __builtin_popcountll(support)));
+            if (picks0.size() >= 2 && (double)picks0.size() >= cfg_.cheap_margin * (double)cfg_.tile_max_ops * share) {
+                std::sort(picks0.begin(), picks0.end());
+                for (long i : picks0) { group.push_back(closed_[(size_t)i]); done[(size_t)i] = 1; }
+                note_tile(tile_pass(group, h0, sink, support));
+                continue;
+            }
+        }
         {   // the cap balances a pass's block phase against its memory time; a pass that would leave only a few clusters
             // for one more sweep over the state (6.6 ms at n = 30 for, on the bench circuit, ONE gate) takes them instead
             size_t left = 0;
@@ -720,10 +764,12 @@ void Scheduler::build_passes(const PassSink &sink) {
         if (group.empty()) { // cannot happen while kmax >= 2; keep the scheduler total anyway
             single_op_pass(closed_[first], sink);
             done[first] = 1;
+            support = all;
         } else if (group.size() == 1) {
-            single_op_pass(group[0], sink);
+            single_op_pass(group[0], sink); // may be a tile pass of its own or a single-gate kernel: count it as dense
+            support = all;
         } else {
-            tile_pass(group, hset, sink);
+            note_tile(tile_pass(group, hset, sink, support == all ? ~0ULL : support));
         }
     }
 }

@@ -125,6 +125,13 @@ struct SchedConfig {
     int local_iters = 0; // level 3: rounds of swap-one-qubit local search on each pass's qubit set
     int objective = 0; // what a pass maximises: 0 blocks, 1 source gates
     int selectors = 1; // level 3: a block may run in a pass whose tile lacks qubits it is block-diagonal in
+    // Qubits that may already be 1 somewhere in the state when the first pass runs (all ones: unknown / dense).  After a
+    // reset it is 0: a tile pass then only visits 2^(|support after it| - n) of the register (engine: qsim_state::support),
+    // so while the support is small the scheduler (a) never takes a qubit outside it into a tile without need and (b)
+    // first tries a pass that stays inside it altogether, keeping it when it absorbs more clusters than its share of a
+    // full sweep is worth (cheap_margin x tile_max_ops x that share).
+    uint64_t initial_support = ~0ULL;
+    double cheap_margin = 1.0;
 };
 
 class Scheduler {
@@ -158,7 +165,8 @@ class Scheduler {
     void fold_2q(const cd U[16], int q_hi, int q_lo, uint32_t gates);
     void build_passes(const PassSink &sink);
     void single_op_pass(const FusedOp &op, const PassSink &sink) const;
-    void tile_pass(const std::vector<FusedOp> &ops, uint64_t hset, const PassSink &sink) const;
+    // prefer: index bits free tile slots are filled from first (the state's support while it is partial); returns the tile's qubit mask
+    uint64_t tile_pass(const std::vector<FusedOp> &ops, uint64_t hset, const PassSink &sink, uint64_t prefer = ~0ULL) const;
     void merge_blocks(std::vector<TileBlock> &blocks) const;
 };
 

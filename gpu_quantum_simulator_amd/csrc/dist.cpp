@@ -957,8 +957,9 @@ extern "C" int qsim_shard_plan_tune(const qsim_shard_plan *p, int shard, qsim_st
     qsim_tune_report total{};
     int locals = 0;
     for (const Step &st : p->plan.steps) locals += !st.exchange;
+    bool exchanged = false; // local steps after the first exchange start from a dense shard, the first one from a reset
     for (const Step &st : p->plan.steps) {
-        if (st.exchange) continue;
+        if (st.exchange) { exchanged = true; continue; }
         qsim_circuit *c = nullptr;
         int rc = qsim_circuit_create(p->plan.m, &c);
         for (const LocalOp &o : st.per_shard[(size_t)shard]) {
@@ -973,7 +974,7 @@ extern "C" int qsim_shard_plan_tune(const qsim_shard_plan *p, int shard, qsim_st
             }
         }
         qsim_tune_report r{};
-        if (rc == QSIM_OK) rc = qsim_tune_circuit(s, c, max_candidates, budget_ms > 0 ? budget_ms / locals : 0.0, &r);
+        if (rc == QSIM_OK) rc = qsim_tune_circuit_from(s, c, max_candidates, budget_ms > 0 ? budget_ms / locals : 0.0, &r, exchanged ? 1 : 0);
         qsim_circuit_free(c);
         if (rc) return cfail(rc, "%s", qsim_last_error());
         total.tile_passes += r.tile_passes; total.already_known += r.already_known; total.passes_tuned += r.passes_tuned;

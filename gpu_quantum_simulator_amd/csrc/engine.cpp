@@ -1233,6 +1233,11 @@ static void feed(Scheduler &sched, const qsim_circuit *c) {
 // order_tile_bits() consults.  The state's contents are clobbered, so it is left reset to |0...0>.  Results never
 // depend on the order; only the pass times do.
 extern "C" int qsim_tune_circuit(qsim_state *s, const qsim_circuit *c, int max_candidates, double budget_ms, qsim_tune_report *rep) {
+    return qsim_tune_circuit_from(s, c, max_candidates, budget_ms, rep, 0);
+}
+
+extern "C" int qsim_tune_circuit_from(qsim_state *s, const qsim_circuit *c, int max_candidates, double budget_ms, qsim_tune_report *rep,
+                                      int dense_start) {
     if (!s || !c) return fail(QSIM_ERR_ARG, "NULL argument");
     if (c->num_q != s->n) return fail(QSIM_ERR_ARG, "circuit has %d qubits, state has %d", c->num_q, s->n);
     if (max_candidates < 1) max_candidates = 1;
@@ -1240,7 +1245,7 @@ extern "C" int qsim_tune_circuit(qsim_state *s, const qsim_circuit *c, int max_c
     if (rc) return rc;
     HIP_TRY(hipSetDevice(s->device));
     Scheduler sched(sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32,
-                                 s->sparse_start ? 0 : ~0ULL)); // the run that follows starts from the reset this call ends with
+                                 s->sparse_start && !dense_start ? 0 : ~0ULL)); // by default the run that follows starts from the reset this call ends with
     feed(sched, c);
     std::vector<Pass> passes;
     sched.finish(passes);

@@ -180,6 +180,10 @@ typedef struct {
     double seconds;       /* wall time spent measuring */
 } qsim_tune_report;
 int qsim_tune_circuit(qsim_state *s, const qsim_circuit *circuit, int max_candidates, double budget_ms, qsim_tune_report *report);
+/* The same for a circuit that will run on a state that is NOT fresh from a reset (dense_start != 0): the schedule of such a
+ * run differs in its first passes (QSIM_OPT_SPARSE_START), e.g. a shard's local gates after its first exchange. */
+int qsim_tune_circuit_from(qsim_state *s, const qsim_circuit *circuit, int max_candidates, double budget_ms, qsim_tune_report *report,
+                           int dense_start);
 long qsim_tune_table_size(void);
 void qsim_tune_table_clear(void);
 int qsim_tune_table_save(const char *path);  /* text, one geometry per line */

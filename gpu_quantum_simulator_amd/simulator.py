@@ -208,11 +208,12 @@ class Simulator:
     def flush(self) -> None:
         check(_lib.load().qsim_flush(self._h))
 
-    def tune(self, circuit: Circuit, max_candidates: int = 32, budget_ms: float = 6000.0) -> dict:
-        """qsim_tune_circuit: times every pass of the circuit's schedule under candidate orders of its tile bits and
-        keeps the fastest per geometry in the library's process-wide table (planning; leaves the state reset)."""
+    def tune(self, circuit: Circuit, max_candidates: int = 32, budget_ms: float = 6000.0, dense_start: bool = False) -> dict:
+        """qsim_tune_circuit(_from): times every pass of the circuit's schedule under candidate orders of its tile bits and
+        keeps the fastest per geometry in the library's process-wide table (planning; leaves the state reset).
+        dense_start: the circuit will run on a state that is not fresh from a reset (its first passes are scheduled differently)."""
         rep = _lib.QsimTuneReport()
-        check(_lib.load().qsim_tune_circuit(self._h, circuit._h, max_candidates, budget_ms, byref(rep)))
+        check(_lib.load().qsim_tune_circuit_from(self._h, circuit._h, max_candidates, budget_ms, byref(rep), 1 if dense_start else 0))
         return rep.as_dict()
 
     def pack_bits_to(self, bits: Sequence[int], dst_ptrs: Sequence[int]) -> None:

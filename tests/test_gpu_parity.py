@@ -1024,3 +1024,28 @@ def test_sparse_start_visits_only_the_support(oracle, tmp_path):
             sim.run(Circuit.from_gates(n, gates[:60]))
             full.write(s0); full.run(Circuit.from_gates(n, gates[:60]))
             assert np.array_equal(sim.read(), full.read())
+
+
+def test_planning_for_a_dense_start(oracle):
+    """qsim_tune_circuit_from(dense_start): the schedule of a circuit that runs on a caller-written (dense) state differs in
+    its first passes from the one after a reset; planning it fills the table for THOSE geometries and changes no result."""
+    n = 17
+    gates = circuits.random_gates(n, 300, 88, "all")
+    c = Circuit.from_gates(n, gates)
+    s0 = _rand_state(n, 3)
+    with Simulator(n, fuse=3, profile=True, tile_bits=10) as sim, Simulator(n, fuse=0) as ref:
+        ref.write(s0); ref.run(c)
+        want = ref.read()                                           # the per-gate kernels, each verified against the oracle
+        lib = _lib.load()
+        lib.qsim_tune_table_clear()
+        rep = sim.tune(c, max_candidates=4, budget_ms=0, dense_start=True)
+        assert rep["passes_tuned"] >= 1 and lib.qsim_tune_table_size() == rep["passes_tuned"]
+        sim.write(s0); sim.reset_stats(); sim.run(c)
+        assert np.max(np.abs(sim.read() - want)) < TOL
+        dense_masks = {hm for k, _, hm, _ in sim.launch_log() if k == "tile"}
+        rep2 = sim.tune(c, max_candidates=4, budget_ms=0, dense_start=True)
+        assert rep2["already_known"] == rep2["tile_passes"]          # every geometry of the dense-start schedule is planned
+        sim.reset(); sim.reset_stats(); sim.run(c); sim.sync()
+        sparse_masks = {hm for k, _, hm, _ in sim.launch_log() if k == "tile"}
+        assert sparse_masks != dense_masks                           # after a reset the first passes are chosen differently
+        lib.qsim_tune_table_clear()

@@ -1401,11 +1401,11 @@ extern "C" int qsim_plan_circuit(const qsim_circuit *c, int fuse, int tile_bits,
     sched.finish(passes);
     memset(out, 0, sizeof *out);
     out->gates = sched.gates_seen();
-    for (const Pass &p : passes) {
+    for (const Pass &p : passes) { // a run from a reset: the first tile passes visit part of the register (Pass::visited)
         out->launches++;
-        out->algorithmic_bytes += p.bytes;
+        out->algorithmic_bytes += p.bytes * p.visited;
         out->k_launches[p.kclass]++;
-        out->k_bytes[p.kclass] += p.bytes;
+        out->k_bytes[p.kclass] += p.bytes * p.visited;
     }
     return QSIM_OK;
 }

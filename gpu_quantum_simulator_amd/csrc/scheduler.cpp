@@ -517,6 +517,10 @@ uint64_t Scheduler::tile_pass(const std::vector<FusedOp> &ops, uint64_t hset, co
     p.blocks.insert(p.blocks.end(), blocks.begin(), blocks.end());
     const uint64_t tmask = lowmask | high;
     if (p.blocks.empty()) return 0; // every block was the identity: nothing is launched, nothing changes
+    if (prefer != ~0ULL) { // the state's support is known: the pass visits the tiles inside support | tile
+        const uint64_t all = cfg_.n >= 64 ? ~0ULL : ((1ULL << cfg_.n) - 1ULL);
+        p.visited = 1.0 / (double)(1ULL << (cfg_.n - __builtin_popcountll((prefer | tmask) & all)));
+    }
     sink(std::move(p));
     return tmask;
 }

@@ -105,7 +105,8 @@ struct Pass {
         for (const TileBlock &b : blocks) g += b.gates;
         return g;
     }
-    double bytes = 0;         // algorithmic bytes this pass must move
+    double bytes = 0;         // algorithmic bytes this pass must move when it sweeps the whole register
+    double visited = 1.0;     // ... times this: the fraction of the register inside the state's support after the pass (tile passes of a run that starts from a reset, SchedConfig::initial_support)
     bool diag_full = false;   // QSIM_K_PHASE executed over every amplitude (d0 != 1 or q < 2)
 };
 

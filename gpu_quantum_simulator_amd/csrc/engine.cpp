@@ -758,22 +758,38 @@ static uint64_t current_support(const qsim_state *s) {
     return s->partial ? s->support : ~0ULL;
 }
 
-static uint64_t queue_key(const qsim_state *s) {
-    uint64_t h = 0xcbf29ce484222325ULL; // FNV-1a over the options that shape a plan and over every queued gate
+// FNV-1a over the options that shape a plan, the state's support and every gate: names a schedule
+static uint64_t gates_key(const qsim_state *s, const QueuedGate *gates, size_t count, uint64_t support) {
+    uint64_t h = 0xcbf29ce484222325ULL;
     auto mix = [&](const void *p, size_t n) {
         const unsigned char *b = (const unsigned char *)p;
         for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ULL; }
     };
-    const int opts[8] = {s->n, s->f32 ? 1 : 0, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, (int)s->queue.size()};
+    const int opts[8] = {s->n, s->f32 ? 1 : 0, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, (int)count};
     mix(opts, sizeof opts);
-    const uint64_t sup = current_support(s); // the schedule depends on where the state is known to be zero
-    mix(&sup, sizeof sup);
-    for (const QueuedGate &g : s->queue) {
+    mix(&support, sizeof support); // the schedule depends on where the state is known to be zero
+    for (size_t i = 0; i < count; i++) {
+        const QueuedGate &g = gates[i];
         const int hd[3] = {g.kind, g.q0, g.q1};
         mix(hd, sizeof hd);
         if (g.kind != QSIM_GATE_CX) mix(g.m, (g.kind == QSIM_GATE_U1 ? 4 : 16) * sizeof(cd));
     }
     return h;
+}
+static uint64_t queue_key(const qsim_state *s) { return gates_key(s, s->queue.data(), s->queue.size(), current_support(s)); }
+
+// Scheduler variant per circuit, decided by the planning step (qsim_tune_circuit): key -> SchedConfig::commute.  Circuits
+// that were never planned use the default.
+static std::mutex g_hints_mu;
+static std::map<uint64_t, int> g_sched_hints;
+static int sched_hint(uint64_t key, int dflt) {
+    std::lock_guard<std::mutex> lock(g_hints_mu);
+    auto it = g_sched_hints.find(key);
+    return it == g_sched_hints.end() ? dflt : it->second;
+}
+static bool have_sched_hints() {
+    std::lock_guard<std::mutex> lock(g_hints_mu);
+    return !g_sched_hints.empty();
 }
 
 extern "C" int qsim_flush(qsim_state *s) {
@@ -784,7 +800,8 @@ extern "C" int qsim_flush(qsim_state *s) {
     HIP_TRY(hipSetDevice(s->device));
     constexpr size_t kMaxPlans = 8, kMaxCachedOps = 4096;
     const bool cacheable = s->plan_cache && s->fuse >= 3 && s->debug_tile_order == 0 && s->queue.size() >= 8;
-    const uint64_t key = cacheable ? queue_key(s) : 0;
+    const bool hinted = s->fuse >= 3 && have_sched_hints();
+    const uint64_t key = (cacheable || hinted) ? queue_key(s) : 0;
     const uint64_t epoch = g_wisdom_epoch.load();
     if (cacheable) {
         for (CachedPlan &pl : s->plans) {
@@ -809,7 +826,9 @@ extern "C" int qsim_flush(qsim_state *s) {
             return QSIM_OK;
         }
     }
-    Scheduler sched(sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32, current_support(s)));
+    SchedConfig scfg = sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32, current_support(s));
+    if (hinted) scfg.commute = sched_hint(key, scfg.commute);
+    Scheduler sched(scfg);
     for (const QueuedGate &g : s->queue) {
         if (g.kind == QSIM_GATE_U1) sched.add_1q(g.m, g.q0);
         else if (g.kind == QSIM_GATE_CX) sched.add_cx(g.q0, g.q1);
@@ -1244,11 +1263,41 @@ extern "C" int qsim_tune_circuit_from(qsim_state *s, const qsim_circuit *c, int 
     int rc = qsim_sync(s);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(s->device));
-    Scheduler sched(sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32,
-                                 s->sparse_start && !dense_start ? 0 : ~0ULL)); // by default the run that follows starts from the reset this call ends with
-    feed(sched, c);
+    SchedConfig scfg = sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32,
+                                    s->sparse_start && !dense_start ? 0 : ~0ULL); // by default the run that follows starts from the reset this call ends with
+    // Which way to schedule THIS circuit (SchedConfig::commute): both are tried, the one whose passes move fewer bytes is
+    // remembered under the key qsim_flush will compute for the same gates, and its passes are the ones measured below.
     std::vector<Pass> passes;
-    sched.finish(passes);
+    {
+        std::vector<QueuedGate> q((size_t)c->count);
+        for (long i = 0; i < c->count; i++) {
+            const qsim_gate_rec &g = c->gates[i];
+            QueuedGate &o = q[(size_t)i];
+            o.kind = g.kind; o.q0 = g.q0; o.q1 = g.kind == QSIM_GATE_U1 ? -1 : g.q1;
+            const double *U = g.kind == QSIM_GATE_U1 ? c->mats2 + 8 * (long)g.mat : g.kind == QSIM_GATE_CX ? nullptr : c->mats4 + 32 * (long)g.mat;
+            for (int k = 0; U && k < (g.kind == QSIM_GATE_U1 ? 4 : 16); k++) o.m[k] = cd(U[2 * k], U[2 * k + 1]);
+        }
+        const uint64_t key = gates_key(s, q.data(), q.size(), scfg.initial_support);
+        double best_cost = 0;
+        int best = scfg.commute;
+        for (int variant = 1; variant >= 0 && s->fuse >= 3; variant--) {
+            SchedConfig v = scfg;
+            v.commute = variant;
+            Scheduler sv(v);
+            feed(sv, c);
+            std::vector<Pass> pv;
+            sv.finish(pv);
+            double cost = 0;
+            for (const Pass &p : pv) cost += p.bytes * p.visited;
+            if (variant == 1 || cost < best_cost * 0.995) { best_cost = cost; best = variant; passes = std::move(pv); }
+        }
+        if (s->fuse < 3) { Scheduler sv(scfg); feed(sv, c); sv.finish(passes); }
+        std::lock_guard<std::mutex> lock(g_hints_mu);
+        const auto it = g_sched_hints.find(key);
+        const int before = it == g_sched_hints.end() ? scfg.commute : it->second;
+        if (best == scfg.commute) g_sched_hints.erase(key); else g_sched_hints[key] = best;
+        if (before != best) g_wisdom_epoch++; // cached plans of this circuit were scheduled the other way
+    }
     qsim_tune_report r{};
     std::vector<const Pass *> todo;
     for (const Pass &p : passes) {
@@ -1387,6 +1436,10 @@ extern "C" long qsim_tune_table_load(const char *path) {
 }
 
 extern "C" void qsim_tune_table_clear(void) {
+    {
+        std::lock_guard<std::mutex> lock(g_hints_mu);
+        g_sched_hints.clear();
+    }
     std::lock_guard<std::mutex> lock(g_wisdom_mu);
     g_wisdom.clear();
     g_wisdom_epoch++;

@@ -109,6 +109,7 @@ Scheduler::Scheduler(const SchedConfig &cfg) : cfg_(cfg), open_(cfg.n > 0 ? cfg.
     if (const char *v = getenv("QSIM_SCHED_MERGE")) cfg_.merge = atoi(v);
     if (const char *v = getenv("QSIM_SCHED_MERGEQ")) cfg_.merge_qubits = atoi(v);
     if (const char *v = getenv("QSIM_SCHED_CHEAP")) cfg_.cheap_margin = atof(v);
+    if (getenv("QSIM_SCHED_NOCOMMUTE")) cfg_.commute = 0;
 }
 
 void Scheduler::close(int idx) {
@@ -547,16 +548,24 @@ void Scheduler::build_passes(const PassSink &sink) {
     std::vector<FusedOp> group;
     struct Cand { long idx; int need; };
 
+    // Order: a cluster may run before an earlier pending one unless one of them MIXES a qubit they share — two clusters that
+    // are both block-diagonal in every shared qubit (controls of CXs, diagonal gates) commute.  (The first version chained
+    // everything on a shared qubit; with ~a quarter of the gates being CXs the controls were most of the chain.)
+    const bool commute = cfg_.selectors && cfg_.commute;
+    auto conflicts = [&](size_t i, uint64_t bm, uint64_t bs) {
+        if (!commute) return (qm[i] & (bm | bs)) != 0;
+        return (must[i] & (bm | bs)) != 0 || (qm[i] & ~must[i] & bm) != 0;
+    };
     // Runnable blocks under the qubits chosen so far, cheapest (fewest new high-qubit slots) first.  A block is
     // runnable when no earlier pending block shares a qubit with it, directly or through a chain of pending blocks
     // (those qubits are "blocked"), so emitting blocks in the order they are picked respects every dependency.
     auto scan = [&](const std::vector<char> &dn, size_t from, size_t to, uint64_t hset, std::vector<Cand> *cands) -> Cand {
         Cand best{-1, 1 << 30};
-        uint64_t blocked = 0;
+        uint64_t bm = 0, bs = 0; // qubits mixed by / merely selecting in the pending clusters passed over so far
         const int used = __builtin_popcountll(hset);
         for (size_t i = from; i < to; i++) {
             if (dn[i]) continue;
-            if (!(qm[i] & blocked)) {
+            if (!conflicts(i, bm, bs)) {
                 const int need = __builtin_popcountll(must[i] & ~lowmask & ~hset);
                 if (used + need <= kmax) {
                     if (cands) cands->push_back({(long)i, need});
@@ -566,8 +575,9 @@ void Scheduler::build_passes(const PassSink &sink) {
                     }
                 }
             }
-            blocked |= qm[i];
-            if (blocked == all) break;
+            bm |= must[i];
+            bs |= qm[i] & ~must[i];
+            if (bm == all) break;
         }
         return best;
     };
@@ -602,18 +612,19 @@ void Scheduler::build_passes(const PassSink &sink) {
     std::vector<long> picks, best_picks;
     bool endgame = false; // few blocks left: search the last pass sets so that no straggler pass remains
     auto eval = [&](const std::vector<char> &dn, size_t from, size_t to, uint64_t S, std::vector<long> *out) {
-        uint64_t blocked = 0;
+        uint64_t bm = 0, bs = 0;
         int score = 0, cnt = 0;
         if (out) out->clear();
         for (size_t i = from; i < to && cnt < cap; i++) {
             if (dn[i]) continue;
-            if (!(qm[i] & blocked) && !(must[i] & ~lowmask & ~S)) {
+            if (!conflicts(i, bm, bs) && !(must[i] & ~lowmask & ~S)) {
                 score += cfg_.objective ? (int)closed_[i].gates : 1;
                 cnt++;
                 if (out) out->push_back((long)i);
             } else {
-                blocked |= qm[i];
-                if (blocked == all) break;
+                bm |= must[i];
+                bs |= qm[i] & ~must[i];
+                if (bm == all) break;
             }
         }
         return score;
@@ -675,16 +686,17 @@ void Scheduler::build_passes(const PassSink &sink) {
             while ((int)picks0.size() < cfg_.tile_max_ops) {
                 long pick = -1;
                 int bestneed = 1 << 30;
-                uint64_t blocked = 0;
+                uint64_t bm = 0, bs = 0;
                 const int used = __builtin_popcountll(h0);
                 for (size_t i = first; i < end0; i++) {
                     if (work0[i]) continue;
-                    if (!(qm[i] & blocked) && !(must[i] & ~lowmask & ~support)) {
+                    if (!conflicts(i, bm, bs) && !(must[i] & ~lowmask & ~support)) {
                         const int need = __builtin_popcountll(must[i] & ~lowmask & ~h0);
                         if (used + need <= kmax && need < bestneed) { bestneed = need; pick = (long)i; if (need == 0) break; }
                     }
-                    blocked |= qm[i];
-                    if (blocked == all) break;
+                    bm |= must[i];
+                    bs |= qm[i] & ~must[i];
+                    if (bm == all) break;
                 }
                 if (pick < 0) break;
                 work0[(size_t)pick] = 1;

@@ -133,6 +133,11 @@ struct SchedConfig {
     // full sweep is worth (cheap_margin x tile_max_ops x that share).
     uint64_t initial_support = ~0ULL;
     double cheap_margin = 1.0;
+    // 1: a cluster may overtake an earlier pending one when both are block-diagonal in every qubit they share (they commute:
+    // controls of CXs, diagonal gates); 0: any shared qubit orders them (round 1).  More freedom is better on average (ten
+    // seeded 1000-gate circuits at n = 30: 892 -> 835 ms in total) but the greedy packing does not use it well on every
+    // circuit, so the planning step (qsim_tune_circuit) schedules both ways and keeps the cheaper one for that circuit.
+    int commute = 1;
 };
 
 class Scheduler {

@@ -251,6 +251,8 @@ class Bench:
         if dist is not None and probe_q is None and not args.no_tune and fuse >= 3:
             tuning = sim.tune(args.tune_candidates, args.tune_ms)  # every rank plans its own shard's passes
             self.fence(sim)
+        if dist is None and probe_q is None and fuse >= 3:
+            sim.choose_schedule(circuit)  # planning, part one: which of the scheduler's two cluster orders this circuit gets
         if dist is None and probe_q is None and not args.no_tune and fuse >= 3:
             run_step()
             self.fence(sim)

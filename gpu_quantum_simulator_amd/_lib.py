@@ -117,6 +117,7 @@ SIGNATURES = {
     "qsim_launch_log": (c_long, [c_void_p, c_long, POINTER(c_int), POINTER(c_int), POINTER(c_uint64), POINTER(c_double)]),
     "qsim_launch_log_order": (c_int, [c_void_p, c_long, POINTER(c_int), POINTER(c_int)]),
     "qsim_tune_circuit": (c_int, [c_void_p, c_void_p, c_int, c_double, POINTER(QsimTuneReport)]),
+    "qsim_choose_schedule": (c_int, [c_void_p, c_void_p]),
     "qsim_tune_circuit_from": (c_int, [c_void_p, c_void_p, c_int, c_double, POINTER(QsimTuneReport), c_int]),
     "qsim_tune_table_size": (c_long, []),
     "qsim_tune_table_clear": (None, []),

@@ -1244,6 +1244,63 @@ static void feed(Scheduler &sched, const qsim_circuit *c) {
     }
 }
 
+// Schedules the circuit both ways (SchedConfig::commute), remembers the one whose passes move fewer bytes under the key
+// qsim_flush will compute for the same gates on a state with this support, and hands its passes back.
+static void choose_schedule(qsim_state *s, const qsim_circuit *c, const SchedConfig &scfg, std::vector<Pass> *out) {
+    std::vector<Pass> passes;
+    if (s->fuse < 3) {
+        Scheduler sv(scfg);
+        feed(sv, c);
+        sv.finish(passes);
+        if (out) *out = std::move(passes);
+        return;
+    }
+    std::vector<QueuedGate> q((size_t)c->count);
+    for (long i = 0; i < c->count; i++) {
+        const qsim_gate_rec &g = c->gates[i];
+        QueuedGate &o = q[(size_t)i];
+        o.kind = g.kind; o.q0 = g.q0; o.q1 = g.kind == QSIM_GATE_U1 ? -1 : g.q1;
+        const double *U = g.kind == QSIM_GATE_U1 ? c->mats2 + 8 * (long)g.mat : g.kind == QSIM_GATE_CX ? nullptr : c->mats4 + 32 * (long)g.mat;
+        for (int k = 0; U && k < (g.kind == QSIM_GATE_U1 ? 4 : 16); k++) o.m[k] = cd(U[2 * k], U[2 * k + 1]);
+    }
+    const uint64_t key = gates_key(s, q.data(), q.size(), scfg.initial_support);
+    double best_cost = 0;
+    int best = scfg.commute;
+    for (int variant = 1; variant >= 0; variant--) {
+        SchedConfig v = scfg;
+        v.commute = variant;
+        Scheduler sv(v);
+        feed(sv, c);
+        std::vector<Pass> pv;
+        sv.finish(pv);
+        double cost = 0;
+        for (const Pass &p : pv) cost += p.bytes * p.visited;
+        if (variant == 1 || cost < best_cost * 0.995) { best_cost = cost; best = variant; passes = std::move(pv); }
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_hints_mu);
+        const auto it = g_sched_hints.find(key);
+        const int before = it == g_sched_hints.end() ? scfg.commute : it->second;
+        if (best == scfg.commute) g_sched_hints.erase(key); else g_sched_hints[key] = best;
+        if (before != best) g_wisdom_epoch++; // cached plans of this circuit were scheduled the other way
+    }
+    if (out) *out = std::move(passes);
+}
+
+// The schedule choice alone (no timing): for a run from a reset and for a run on a dense state.
+extern "C" int qsim_choose_schedule(qsim_state *s, const qsim_circuit *c) {
+    if (!s || !c) return fail(QSIM_ERR_ARG, "NULL argument");
+    if (c->num_q != s->n) return fail(QSIM_ERR_ARG, "circuit has %d qubits, state has %d", c->num_q, s->n);
+    const int rc = qsim_flush(s);
+    if (rc) return rc;
+    for (int dense = 0; dense < 2; dense++) {
+        if (!dense && !s->sparse_start) continue;
+        const SchedConfig scfg = sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32, dense ? ~0ULL : 0);
+        choose_schedule(s, c, scfg, nullptr);
+    }
+    return QSIM_OK;
+}
+
 // ---- measured pass geometry -------------------------------------------------------------------------------------------
 // Plans the circuit exactly as qsim_run_circuit + qsim_flush would and, for every tile pass whose geometry is not in the
 // table yet, times the pass (its real blocks, on whatever the state buffer holds) under candidate orders of its high
@@ -1265,39 +1322,9 @@ extern "C" int qsim_tune_circuit_from(qsim_state *s, const qsim_circuit *c, int 
     HIP_TRY(hipSetDevice(s->device));
     SchedConfig scfg = sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32,
                                     s->sparse_start && !dense_start ? 0 : ~0ULL); // by default the run that follows starts from the reset this call ends with
-    // Which way to schedule THIS circuit (SchedConfig::commute): both are tried, the one whose passes move fewer bytes is
-    // remembered under the key qsim_flush will compute for the same gates, and its passes are the ones measured below.
+    // Which way to schedule THIS circuit (SchedConfig::commute) is decided first; its passes are the ones measured below.
     std::vector<Pass> passes;
-    {
-        std::vector<QueuedGate> q((size_t)c->count);
-        for (long i = 0; i < c->count; i++) {
-            const qsim_gate_rec &g = c->gates[i];
-            QueuedGate &o = q[(size_t)i];
-            o.kind = g.kind; o.q0 = g.q0; o.q1 = g.kind == QSIM_GATE_U1 ? -1 : g.q1;
-            const double *U = g.kind == QSIM_GATE_U1 ? c->mats2 + 8 * (long)g.mat : g.kind == QSIM_GATE_CX ? nullptr : c->mats4 + 32 * (long)g.mat;
-            for (int k = 0; U && k < (g.kind == QSIM_GATE_U1 ? 4 : 16); k++) o.m[k] = cd(U[2 * k], U[2 * k + 1]);
-        }
-        const uint64_t key = gates_key(s, q.data(), q.size(), scfg.initial_support);
-        double best_cost = 0;
-        int best = scfg.commute;
-        for (int variant = 1; variant >= 0 && s->fuse >= 3; variant--) {
-            SchedConfig v = scfg;
-            v.commute = variant;
-            Scheduler sv(v);
-            feed(sv, c);
-            std::vector<Pass> pv;
-            sv.finish(pv);
-            double cost = 0;
-            for (const Pass &p : pv) cost += p.bytes * p.visited;
-            if (variant == 1 || cost < best_cost * 0.995) { best_cost = cost; best = variant; passes = std::move(pv); }
-        }
-        if (s->fuse < 3) { Scheduler sv(scfg); feed(sv, c); sv.finish(passes); }
-        std::lock_guard<std::mutex> lock(g_hints_mu);
-        const auto it = g_sched_hints.find(key);
-        const int before = it == g_sched_hints.end() ? scfg.commute : it->second;
-        if (best == scfg.commute) g_sched_hints.erase(key); else g_sched_hints[key] = best;
-        if (before != best) g_wisdom_epoch++; // cached plans of this circuit were scheduled the other way
-    }
+    choose_schedule(s, c, scfg, &passes);
     qsim_tune_report r{};
     std::vector<const Pass *> todo;
     for (const Pass &p : passes) {

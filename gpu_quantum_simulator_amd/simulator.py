@@ -208,6 +208,10 @@ class Simulator:
     def flush(self) -> None:
         check(_lib.load().qsim_flush(self._h))
 
+    def choose_schedule(self, circuit: Circuit) -> None:
+        """qsim_choose_schedule: the schedule choice of the planning step alone (no timing)."""
+        check(_lib.load().qsim_choose_schedule(self._h, circuit._h))
+
     def tune(self, circuit: Circuit, max_candidates: int = 32, budget_ms: float = 6000.0, dense_start: bool = False) -> dict:
         """qsim_tune_circuit(_from): times every pass of the circuit's schedule under candidate orders of its tile bits and
         keeps the fastest per geometry in the library's process-wide table (planning; leaves the state reset).

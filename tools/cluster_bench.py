@@ -5,6 +5,7 @@ from gpu_quantum_simulator_amd import Circuit, Cluster, Simulator, circuits
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 c = Circuit.from_gates(n, circuits.random_gates(n, 1000, 20240117 + n, "all"))
 with Simulator(n) as sim:
+    sim.choose_schedule(c)
     def body():
         sim.reset(); sim.run(c); sim.sync()
     body()

@@ -20,6 +20,7 @@ def log(sim):
 
 
 with Simulator(n, fuse=3, profile=True, precision=precision, **opts) as sim:
+    sim.choose_schedule(c)  # the schedule bench.py's planning step picks for this circuit
     full = log(sim)
     sim.set_option(_lib.OPT_DEBUG_SKIP_OPS, 1)
     mem = log(sim)

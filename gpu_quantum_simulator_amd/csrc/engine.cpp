@@ -780,12 +780,16 @@ static uint64_t queue_key(const qsim_state *s) { return gates_key(s, s->queue.da
 
 // Scheduler variant per circuit, decided by the planning step (qsim_tune_circuit): key -> SchedConfig::commute.  Circuits
 // that were never planned use the default.
+struct SchedHint { int commute; double cheap_margin; int lookahead; };
 static std::mutex g_hints_mu;
-static std::map<uint64_t, int> g_sched_hints;
-static int sched_hint(uint64_t key, int dflt) {
+static std::map<uint64_t, SchedHint> g_sched_hints;
+static void apply_sched_hint(uint64_t key, SchedConfig &cfg) {
     std::lock_guard<std::mutex> lock(g_hints_mu);
     auto it = g_sched_hints.find(key);
-    return it == g_sched_hints.end() ? dflt : it->second;
+    if (it == g_sched_hints.end()) return;
+    cfg.commute = it->second.commute;
+    cfg.cheap_margin = it->second.cheap_margin;
+    cfg.lookahead = it->second.lookahead;
 }
 static bool have_sched_hints() {
     std::lock_guard<std::mutex> lock(g_hints_mu);
@@ -827,7 +831,7 @@ extern "C" int qsim_flush(qsim_state *s) {
         }
     }
     SchedConfig scfg = sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32, current_support(s));
-    if (hinted) scfg.commute = sched_hint(key, scfg.commute);
+    if (hinted) apply_sched_hint(key, scfg);
     Scheduler sched(scfg);
     for (const QueuedGate &g : s->queue) {
         if (g.kind == QSIM_GATE_U1) sched.add_1q(g.m, g.q0);
@@ -1244,8 +1248,8 @@ static void feed(Scheduler &sched, const qsim_circuit *c) {
     }
 }
 
-// Schedules the circuit both ways (SchedConfig::commute), remembers the one whose passes move fewer bytes under the key
-// qsim_flush will compute for the same gates on a state with this support, and hands its passes back.
+// Schedules the circuit under a handful of scheduler settings, remembers the one whose passes move the fewest bytes under
+// the key qsim_flush will compute for the same gates on a state with this support, and hands its passes back.
 static void choose_schedule(qsim_state *s, const qsim_circuit *c, const SchedConfig &scfg, std::vector<Pass> *out) {
     std::vector<Pass> passes;
     if (s->fuse < 3) {
@@ -1264,25 +1268,34 @@ static void choose_schedule(qsim_state *s, const qsim_circuit *c, const SchedCon
         for (int k = 0; U && k < (g.kind == QSIM_GATE_U1 ? 4 : 16); k++) o.m[k] = cd(U[2 * k], U[2 * k + 1]);
     }
     const uint64_t key = gates_key(s, q.data(), q.size(), scfg.initial_support);
+    // the variants: clusters may / may not overtake (commute), how eagerly passes inside the support are kept (cheap_margin),
+    // one more pass of lookahead where the local search is on; the default comes first and wins ties
+    std::vector<SchedHint> variants;
+    for (int com = 1; com >= 0; com--)
+        for (double mar : {scfg.cheap_margin, 2.0 * scfg.cheap_margin})
+            for (int la = scfg.lookahead; la <= scfg.lookahead + (scfg.lookahead >= 1 ? 1 : 0); la++) variants.push_back({com, mar, la});
     double best_cost = 0;
-    int best = scfg.commute;
-    for (int variant = 1; variant >= 0; variant--) {
+    size_t best = 0;
+    for (size_t vi = 0; vi < variants.size(); vi++) {
         SchedConfig v = scfg;
-        v.commute = variant;
+        v.commute = variants[vi].commute; v.cheap_margin = variants[vi].cheap_margin; v.lookahead = variants[vi].lookahead;
         Scheduler sv(v);
         feed(sv, c);
         std::vector<Pass> pv;
         sv.finish(pv);
         double cost = 0;
         for (const Pass &p : pv) cost += p.bytes * p.visited;
-        if (variant == 1 || cost < best_cost * 0.995) { best_cost = cost; best = variant; passes = std::move(pv); }
+        if (vi == 0 || cost < best_cost * 0.995) { best_cost = cost; best = vi; passes = std::move(pv); }
     }
     {
         std::lock_guard<std::mutex> lock(g_hints_mu);
         const auto it = g_sched_hints.find(key);
-        const int before = it == g_sched_hints.end() ? scfg.commute : it->second;
-        if (best == scfg.commute) g_sched_hints.erase(key); else g_sched_hints[key] = best;
-        if (before != best) g_wisdom_epoch++; // cached plans of this circuit were scheduled the other way
+        const SchedHint dflt{scfg.commute, scfg.cheap_margin, scfg.lookahead};
+        const SchedHint before = it == g_sched_hints.end() ? dflt : it->second;
+        const SchedHint now = variants[best];
+        if (best == 0) g_sched_hints.erase(key); else g_sched_hints[key] = now;
+        if (before.commute != now.commute || before.cheap_margin != now.cheap_margin || before.lookahead != now.lookahead)
+            g_wisdom_epoch++; // cached plans of this circuit were scheduled another way
     }
     if (out) *out = std::move(passes);
 }

@@ -180,9 +180,10 @@ typedef struct {
     double seconds;       /* wall time spent measuring */
 } qsim_tune_report;
 int qsim_tune_circuit(qsim_state *s, const qsim_circuit *circuit, int max_candidates, double budget_ms, qsim_tune_report *report);
-/* Only the first half of that planning step, without any timing: schedules the circuit both ways the scheduler knows
- * (clusters that commute may or may not overtake each other), keeps the cheaper one for this circuit — for a run from a
- * reset and for a run on a dense state — and returns.  qsim_tune_circuit does this too. */
+/* Only the first half of that planning step, without any timing: schedules the circuit under a handful of scheduler
+ * settings (clusters that commute may or may not overtake each other, ...), keeps the one whose passes move the fewest
+ * bytes for this circuit — for a run from a reset and for a run on a dense state — and returns.  qsim_tune_circuit does
+ * this too. */
 int qsim_choose_schedule(qsim_state *s, const qsim_circuit *circuit);
 /* The same for a circuit that will run on a state that is NOT fresh from a reset (dense_start != 0): the schedule of such a
  * run differs in its first passes (QSIM_OPT_SPARSE_START), e.g. a shard's local gates after its first exchange. */

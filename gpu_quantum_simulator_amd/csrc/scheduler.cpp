@@ -110,6 +110,7 @@ Scheduler::Scheduler(const SchedConfig &cfg) : cfg_(cfg), open_(cfg.n > 0 ? cfg.
     if (const char *v = getenv("QSIM_SCHED_MERGEQ")) cfg_.merge_qubits = atoi(v);
     if (const char *v = getenv("QSIM_SCHED_CHEAP")) cfg_.cheap_margin = atof(v);
     if (getenv("QSIM_SCHED_NOCOMMUTE")) cfg_.commute = 0;
+    if (const char *v = getenv("QSIM_SCHED_CAP")) { cfg_.tile_max_ops = atoi(v); cfg_.tail_max_ops = 0; }
 }
 
 void Scheduler::close(int idx) {

@@ -20,6 +20,7 @@ OPT_DEBUG_TILE_ORDER = 12
 OPT_PLAN_CACHE = 13
 OPT_PINGPONG = 14
 OPT_SPARSE_START = 15
+OPT_DEBUG_PLAN_KEY = 16
 K_NAMES = ("init", "gate1", "gate1_lo", "phase", "cx", "gate2", "tile", "pack")
 K_COUNT = len(K_NAMES)
 
@@ -41,6 +42,14 @@ class QsimTuneReport(ctypes.Structure):
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class QsimExchangeRoles(ctypes.Structure):
+    _fields_ = [("mine", c_int), ("empty_before", c_int), ("empty_after", c_int), ("keep_own", c_int),
+                ("send", ctypes.c_uint32), ("recv", ctypes.c_uint32), ("unread", ctypes.c_uint32), ("new_support", c_uint64)]
+
+    def as_dict(self) -> dict:
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
 SCHED_CB = ctypes.CFUNCTYPE(None, c_void_p, c_int, c_int, c_int, POINTER(c_int), c_int, POINTER(c_double), c_int)
@@ -68,6 +77,7 @@ SIGNATURES = {
     "qsim_apply_2q": (c_int, [c_void_p, _DP, c_int, c_int]),
     "qsim_flush": (c_int, [c_void_p]),
     "qsim_sync": (c_int, [c_void_p]),
+    "qsim_plan_cache_stats": (c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
     "qsim_read": (c_int, [c_void_p, c_uint64, c_uint64, _DP]),
     "qsim_write": (c_int, [c_void_p, c_uint64, c_uint64, _DP]),
     "qsim_norm2": (c_int, [c_void_p, _DP]),
@@ -80,6 +90,17 @@ SIGNATURES = {
     "qsim_pack_bits_to": (c_int, [c_void_p, POINTER(c_int), c_int, POINTER(c_void_p)]),
     "qsim_swap_buffer": (c_int, [c_void_p, POINTER(c_void_p)]),
     "qsim_set_spare_buffer": (c_int, [c_void_p, c_void_p]),
+    "qsim_set_support": (c_int, [c_void_p, c_uint64]),
+    "qsim_get_support": (c_int, [c_void_p, POINTER(c_uint64), POINTER(c_int), _DP]),
+    "qsim_pack_bits_sparse": (c_int, [c_void_p, POINTER(c_int), c_int, c_void_p, POINTER(c_void_p), ctypes.c_uint32]),
+    "qsim_state_buffer": (c_void_p, [c_void_p]),
+    "qsim_flush_pack": (c_int, [c_void_p, POINTER(c_int), c_int, POINTER(c_int), c_uint64, c_void_p, c_uint64, ctypes.c_uint32, POINTER(c_void_p), POINTER(c_int)]),
+    "qsim_cluster_pack_counts": (c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
+    "qsim_rank_comm_pack_counts": (c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
+    "qsim_cluster_exchange_bytes_moved": (c_int, [c_void_p, _DP]),
+    "qsim_shard_plan_step_support": (c_int, [c_void_p, c_int, POINTER(c_uint64), POINTER(c_uint64)]),
+    "qsim_rank_comm_exchange_step": (c_int, [c_void_p, c_void_p, c_int]),
+    "qsim_shard_plan_exchange_roles": (c_int, [c_void_p, c_int, c_int, POINTER(QsimExchangeRoles)]),
     "qsim_block_prob_masked": (c_int, [c_void_p, c_uint64, c_uint64, _DP]),
     "qsim_gather_masked": (c_int, [c_void_p, c_uint64, c_uint64, _DP]),
     "qsim_scale": (c_int, [c_void_p, c_double, c_double]),
@@ -116,6 +137,7 @@ SIGNATURES = {
     "qsim_reset_stats": (c_int, [c_void_p]),
     "qsim_launch_log": (c_long, [c_void_p, c_long, POINTER(c_int), POINTER(c_int), POINTER(c_uint64), POINTER(c_double)]),
     "qsim_launch_log_order": (c_int, [c_void_p, c_long, POINTER(c_int), POINTER(c_int)]),
+    "qsim_launch_log_visited": (c_int, [c_void_p, c_long, _DP]),
     "qsim_tune_circuit": (c_int, [c_void_p, c_void_p, c_int, c_double, POINTER(QsimTuneReport)]),
     "qsim_choose_schedule": (c_int, [c_void_p, c_void_p]),
     "qsim_tune_circuit_from": (c_int, [c_void_p, c_void_p, c_int, c_double, POINTER(QsimTuneReport), c_int]),

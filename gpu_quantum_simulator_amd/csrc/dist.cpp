@@ -47,6 +47,12 @@ struct Step {
     bool exchange = false;
     std::vector<int> J, Lsel;                    // exchange: shard-id bits and local positions, ascending, paired
     std::vector<std::vector<LocalOp>> per_shard; // local: ops for every shard
+    // exchange: where the state can be non-zero just before it, as PHYSICAL bit sets (local positions / shard-id bits).  A run
+    // starts from |0...0> (quantum_simulator.c:175-177) and a qubit stays |0> until a gate mixes it (a non-diagonal 1-qubit
+    // gate, or a CX onto it whose control may be 1), so every amplitude with a 1 at a qubit outside this set is exactly
+    // zero.  The same on every rank (it follows from the gate list alone), which is what lets an exchange leave out the
+    // blocks of shards that hold nothing and lets the receivers keep visiting only the part of the shard that can be non-zero.
+    uint64_t mixed_local = 0, mixed_rank = 0;
 };
 
 struct Plan {
@@ -102,6 +108,7 @@ bool build_plan_policy(int n, int p, const std::vector<LGate> &gates, Plan &plan
     for (int q = 0; q < n; q++) pos[q] = q;
     std::vector<LGate> remaining(gates);
     bool first = true;
+    uint64_t mixed = 0; // logical qubits that may be 1 somewhere in the state (Step::mixed_local / mixed_rank)
     while (!remaining.empty()) {
         if (p && first) { // free initial placement
             std::vector<int> ng = choose_globals(remaining, pos, n, p, m);
@@ -125,6 +132,10 @@ bool build_plan_policy(int n, int p, const std::vector<LGate> &gates, Plan &plan
             for (int k = 0; k < c; k++) ok = ok && pos[q[k]] < m;
             if (ok) run.push_back(g);
             else { blocked |= qs; deferred.push_back(g); }
+        }
+        for (const LGate &g : run) { // in program order
+            if (g.kind == QSIM_GATE_CX) { if (g.q0 != g.q1 && (mixed >> g.q0 & 1ULL)) mixed |= 1ULL << g.q1; }
+            else if (!g.diag()) mixed |= 1ULL << g.q0;
         }
         if (!run.empty()) {
             Step st;
@@ -168,6 +179,8 @@ bool build_plan_policy(int n, int p, const std::vector<LGate> &gates, Plan &plan
             st.exchange = true;
             for (int q : outgoing) st.Lsel.push_back(pos[q]);
             for (int q : incoming) st.J.push_back(pos[q] - m);
+            for (int q = 0; q < n; q++)
+                if (mixed >> q & 1ULL) (pos[q] < m ? st.mixed_local : st.mixed_rank) |= 1ULL << (pos[q] < m ? pos[q] : pos[q] - m);
             std::vector<int> np(pos);
             for (int q = 0; q < n; q++)
                 if (pos[q] < m && std::find(st.Lsel.begin(), st.Lsel.end(), pos[q]) == st.Lsel.end()) {
@@ -233,6 +246,58 @@ void peers_of(int rank, const std::vector<int> &J, int &mine, std::vector<int> &
     }
 }
 
+// Who sends what in one exchange, for one rank, when only part of the register can be non-zero (Step::mixed_*).  A shard whose
+// id has a 1 at a shard-id bit outside mixed_rank holds nothing; after the exchange the J bits of its id carry the qubits that
+// sat at the local positions Lsel, so a shard is empty afterwards when one of THOSE is outside mixed_local.  Nothing travels
+// from or to an empty shard, and a receiver's new contents can only be non-zero where the local index stays inside
+// `new_support`: the surviving mixed local positions, moved down over the ones that left, plus the top k positions (the
+// sender's member index) for the shard-id bits that were mixed.
+struct Roles {
+    int mine = 0;
+    std::vector<int> members;
+    bool empty_before = false, empty_after = false;
+    uint32_t send = 0, recv = 0; // bit b: block b goes to / comes from members[b] (never bit `mine`)
+    bool keep_own = false;       // block `mine` stays here and holds data
+    uint32_t unread = 0;         // blocks of this rank's packed layout nobody looks at
+    uint64_t new_support = 0;
+};
+Roles roles_of(int rank, int m, const Step &st) {
+    Roles r;
+    const int k = (int)st.J.size();
+    peers_of(rank, st.J, r.mine, r.members);
+    uint32_t jmask = 0, jin = 0, lin = 0;
+    uint64_t lsel = 0;
+    for (int i = 0; i < k; i++) {
+        jmask |= 1u << st.J[i];
+        lsel |= 1ULL << st.Lsel[i];
+        if (st.mixed_rank >> st.J[i] & 1ULL) jin |= 1u << i;
+        if (st.mixed_local >> st.Lsel[i] & 1ULL) lin |= 1u << i;
+    }
+    const bool base_ok = (((uint64_t)rank & ~(uint64_t)jmask) & ~st.mixed_rank) == 0;
+    auto before = [&](int b) { return !base_ok || ((uint32_t)b & ~jin) != 0; }; // member b holds nothing before / after
+    auto after = [&](int b) { return !base_ok || ((uint32_t)b & ~lin) != 0; };
+    r.empty_before = before(r.mine);
+    r.empty_after = after(r.mine);
+    for (int b = 0; b < (1 << k); b++) {
+        if (after(b)) r.unread |= 1u << b;
+        if (b == r.mine) continue;
+        if (!r.empty_before && !after(b)) r.send |= 1u << b;
+        if (!r.empty_after && !before(b)) r.recv |= 1u << b;
+    }
+    r.keep_own = !r.empty_before && !r.empty_after;
+    for (int b = 0; b < m; b++) {
+        if (!(st.mixed_local >> b & 1ULL) || (lsel >> b & 1ULL)) continue;
+        r.new_support |= 1ULL << (b - __builtin_popcountll(lsel & ((1ULL << b) - 1ULL)));
+    }
+    for (int i = 0; i < k; i++)
+        if (jin >> i & 1u) r.new_support |= 1ULL << (m - k + i);
+    return r;
+}
+// What the shard's engine is told once the blocks are in place.
+int settle(qsim_state *s, const Roles &r) {
+    return r.empty_after ? qsim_reset_shard(s, 0) : qsim_set_support(s, r.new_support);
+}
+
 } // namespace
 
 struct qsim_cluster {
@@ -242,12 +307,19 @@ struct qsim_cluster {
     std::vector<double2 *> scratch;
     std::vector<int> pos; // logical -> physical after the last run
     uint64_t exchanges = 0;
-    double exchange_bytes = 0; // per shard, summed over exchanges
+    double exchange_bytes = 0;       // per shard, summed over exchanges, if every block travelled (the dense figure)
+    double exchange_bytes_moved = 0; // what the shards together really sent (blocks of and for empty shards stay home)
     // How blocks travel: every shard on its own device -> RCCL (one ncclGroup of sends + recvs per exchange, on the shard
     // streams); every shard on the SAME device (virtual shards) -> the pack kernel writes its blocks straight into the
     // members' spare buffers and the buffers change roles; anything else -> pack + device-to-device copies.
     std::vector<ncclComm_t> comms;
     bool same_device = false;
+    // same_device: the shards' state buffers are slices of ONE allocation and their scratch buffers slices of another, so
+    // "block b of member j's new contents" is an index of the scratch pool and the re-layout of an exchange is a permutation
+    // of index bits across the whole pool (qsim_flush_pack) — the last tile pass before an exchange writes straight there.
+    char *pool[2] = {nullptr, nullptr};
+    int state_pool = 0; // which pool the states are in (exchanges flip it)
+    uint64_t fused_packs = 0, separate_packs = 0;
     std::vector<hipEvent_t> packed; // per shard: its pack of the current exchange has finished
 };
 
@@ -270,9 +342,11 @@ extern "C" void qsim_cluster_destroy(qsim_cluster *c) {
     for (size_t r = 0; r < c->shard.size(); r++) {
         (void)hipSetDevice(c->devices[r]);
         if (r < c->packed.size() && c->packed[r]) (void)hipEventDestroy(c->packed[r]);
-        if (c->scratch[r]) (void)hipFree(c->scratch[r]);
+        if (c->scratch[r] && !c->pool[0]) (void)hipFree(c->scratch[r]);
         qsim_destroy(c->shard[r]);
     }
+    for (char *pl : c->pool)
+        if (pl) (void)hipFree(pl);
     delete c;
 }
 
@@ -289,15 +363,29 @@ extern "C" int qsim_cluster_create(qsim_cluster **out, int num_q, int num_shards
     c->n = num_q; c->p = p; c->m = num_q - p; c->P = num_shards;
     c->pos.resize(num_q);
     for (int q = 0; q < num_q; q++) c->pos[q] = q;
+    bool one_device = p > 0;
     for (int r = 0; r < num_shards; r++) {
         const int dev = devices ? devices[r] : (r % ndev);
         if (dev < 0 || dev >= ndev) { qsim_cluster_destroy(c); return cfail(QSIM_ERR_ARG, "device %d out of range", dev); }
         c->devices.push_back(dev);
+        one_device = one_device && dev == c->devices[0];
+    }
+    if (one_device) { // virtual shards: two pools, see qsim_cluster::pool
+        (void)hipSetDevice(c->devices[0]);
+        for (int i = 0; i < 2; i++)
+            if (hipMalloc((void **)&c->pool[i], (size_t)16 << num_q) != hipSuccess) {
+                (void)hipGetLastError();
+                qsim_cluster_destroy(c);
+                return cfail(QSIM_ERR_ALLOC, "Malloc error");
+            }
+    }
+    for (int r = 0; r < num_shards; r++) {
+        const int dev = c->devices[r];
         qsim_state *s = nullptr;
-        int rc = qsim_create(&s, c->m, dev);
+        int rc = c->pool[0] ? qsim_create_external(&s, c->m, dev, c->pool[0] + ((size_t)r * 16 << c->m)) : qsim_create(&s, c->m, dev);
         c->shard.push_back(s);
-        c->scratch.push_back(nullptr);
-        if (rc == QSIM_OK && p > 0) {
+        c->scratch.push_back(c->pool[1] ? (double2 *)(c->pool[1] + ((size_t)r * 16 << c->m)) : nullptr);
+        if (rc == QSIM_OK && p > 0 && !c->pool[0]) {
             (void)hipSetDevice(dev);
             if (hipMalloc((void **)&c->scratch[r], (size_t)16 << c->m) != hipSuccess) rc = QSIM_ERR_ALLOC;
         }
@@ -373,7 +461,9 @@ extern "C" int qsim_cluster_reset(qsim_cluster *c) {
     return QSIM_OK;
 }
 
-static int apply_local(qsim_cluster *c, const Step &st) {
+// flush: launch every shard's passes now.  The local step in front of an exchange leaves them queued: the exchange flushes
+// them itself, so that the last tile pass can do the exchange's re-layout (qsim_flush_pack).
+static int apply_local(qsim_cluster *c, const Step &st, bool flush) {
     for (int r = 0; r < c->P; r++) {
         qsim_state *s = c->shard[r];
         for (const LocalOp &o : st.per_shard[r]) {
@@ -386,7 +476,7 @@ static int apply_local(qsim_cluster *c, const Step &st) {
             } else rc = qsim_scale(s, o.m[0].real(), o.m[0].imag());
             if (rc) return cfail(rc, "%s", qsim_last_error());
         }
-        const int rc = qsim_flush(s); // every shard's passes are in flight before the next one is scheduled
+        const int rc = flush ? qsim_flush(s) : QSIM_OK; // every shard's passes are in flight before the next one is scheduled
         if (rc) return cfail(rc, "%s", qsim_last_error());
     }
     return QSIM_OK;
@@ -398,14 +488,27 @@ static int apply_local(qsim_cluster *c, const Step &st) {
 static int exchange_direct(qsim_cluster *c, const Step &st) {
     const int k = (int)st.J.size();
     const size_t blk_bytes = ((size_t)16 << c->m) >> k;
+    std::vector<Roles> roles;
+    for (int r = 0; r < c->P; r++) roles.push_back(roles_of(r, c->m, st));
+    char *out_pool = c->pool[1 - c->state_pool];
+    int to[3] = {0, 0, 0};
+    uint32_t jmask = 0;
+    for (int j = 0; j < k; j++) { to[j] = c->m + st.J[j]; jmask |= 1u << st.J[j]; }
     for (int r = 0; r < c->P; r++) {
-        int mine;
-        std::vector<int> members;
-        peers_of(r, st.J, mine, members);
-        void *dsts[8];
-        for (int j = 0; j < (1 << k); j++) dsts[j] = (char *)c->scratch[members[j]] + (size_t)mine * blk_bytes;
-        const int rc = qsim_pack_bits_to(c->shard[r], st.Lsel.data(), k, dsts);
-        if (rc) return cfail(rc, "%s", qsim_last_error());
+        const Roles &ro = roles[(size_t)r];
+        if (!ro.empty_before) {
+            // destination of this shard's amplitudes inside the scratch pool: shard id = its own with the J bits replaced by the
+            // amplitude's Lsel bits (to[]), block `mine` of that shard, the other local bits closed up below
+            const uint64_t konst = ((uint64_t)((uint32_t)r & ~jmask) << c->m) | ((uint64_t)ro.mine << (c->m - k));
+            int fused = 0;
+            const int rc = qsim_flush_pack(c->shard[r], st.Lsel.data(), k, to, konst, out_pool, st.mixed_local, ro.unread, nullptr, &fused);
+            if (rc) return cfail(rc, "%s", qsim_last_error());
+            (fused ? c->fused_packs : c->separate_packs)++;
+            c->exchange_bytes_moved += (double)blk_bytes * __builtin_popcount(ro.send);
+        } else {
+            const int rc = qsim_flush(c->shard[r]); // an empty shard: its queue is dropped, nothing to pack
+            if (rc) return cfail(rc, "%s", qsim_last_error());
+        }
         if (hipEventRecord(c->packed[r], (hipStream_t)qsim_stream(c->shard[r])) != hipSuccess) return cfail(QSIM_ERR_DEVICE, "event record failed");
     }
     // every stream waits for every pack: the members' packs filled this shard's new buffer, and nobody may write into a
@@ -416,10 +519,12 @@ static int exchange_direct(qsim_cluster *c, const Step &st) {
                 return cfail(QSIM_ERR_DEVICE, "stream wait failed");
     for (int r = 0; r < c->P; r++) {
         void *buf = c->scratch[r];
-        const int rc = qsim_swap_buffer(c->shard[r], &buf);
+        int rc = qsim_swap_buffer(c->shard[r], &buf);
+        if (rc == QSIM_OK) rc = settle(c->shard[r], roles[(size_t)r]);
         if (rc) return cfail(rc, "%s", qsim_last_error());
         c->scratch[r] = (double2 *)buf;
     }
+    c->state_pool = 1 - c->state_pool;
     return QSIM_OK;
 }
 
@@ -430,36 +535,41 @@ static int exchange_direct(qsim_cluster *c, const Step &st) {
 static int exchange_rccl(qsim_cluster *c, const Step &st) {
     const int k = (int)st.J.size();
     const size_t blk_bytes = ((size_t)16 << c->m) >> k;
+    std::vector<Roles> roles;
+    for (int r = 0; r < c->P; r++) roles.push_back(roles_of(r, c->m, st));
     for (int r = 0; r < c->P; r++) {
-        const int rc = qsim_pack_bits(c->shard[r], st.Lsel.data(), k, c->scratch[r]);
+        int fused = 0;
+        const int rc = roles[(size_t)r].empty_before ? qsim_flush(c->shard[r])
+                                                     : qsim_flush_pack(c->shard[r], st.Lsel.data(), k, nullptr, 0, c->scratch[r], st.mixed_local, roles[(size_t)r].unread, nullptr, &fused);
         if (rc) return cfail(rc, "%s", qsim_last_error());
+        if (!roles[(size_t)r].empty_before) (fused ? c->fused_packs : c->separate_packs)++;
     }
+    std::vector<char *> state((size_t)c->P);
+    for (int r = 0; r < c->P; r++) state[(size_t)r] = (char *)qsim_state_buffer(c->shard[r]);
     ncclResult_t nr = ncclGroupStart();
     for (int r = 0; r < c->P && nr == ncclSuccess; r++) {
-        int mine;
-        std::vector<int> members;
-        peers_of(r, st.J, mine, members);
-        char *state = (char *)qsim_device_ptr(c->shard[r]);
+        const Roles &ro = roles[(size_t)r];
         const char *scr = (const char *)c->scratch[r];
         hipStream_t stream = (hipStream_t)qsim_stream(c->shard[r]);
         (void)hipSetDevice(c->devices[r]);
         for (int b = 0; b < (1 << k) && nr == ncclSuccess; b++) {
-            if (b == mine) continue;
-            nr = ncclSend(scr + (size_t)b * blk_bytes, blk_bytes / 8, ncclDouble, members[b], c->comms[r], stream);
-            if (nr == ncclSuccess) nr = ncclRecv(state + (size_t)b * blk_bytes, blk_bytes / 8, ncclDouble, members[b], c->comms[r], stream);
+            if (ro.send >> b & 1u) nr = ncclSend(scr + (size_t)b * blk_bytes, blk_bytes / 8, ncclDouble, ro.members[b], c->comms[r], stream);
+            if (nr == ncclSuccess && (ro.recv >> b & 1u))
+                nr = ncclRecv(state[(size_t)r] + (size_t)b * blk_bytes, blk_bytes / 8, ncclDouble, ro.members[b], c->comms[r], stream);
         }
+        c->exchange_bytes_moved += (double)blk_bytes * __builtin_popcount(ro.send);
     }
     const ncclResult_t ne = ncclGroupEnd();
     if (nr == ncclSuccess) nr = ne;
     if (nr != ncclSuccess) return cfail(QSIM_ERR_DEVICE, "RCCL exchange failed: %s", ncclGetErrorString(nr));
     for (int r = 0; r < c->P; r++) { // the block a shard keeps
-        int mine;
-        std::vector<int> members;
-        peers_of(r, st.J, mine, members);
+        const Roles &ro = roles[(size_t)r];
         (void)hipSetDevice(c->devices[r]);
-        if (hipMemcpyAsync((char *)qsim_device_ptr(c->shard[r]) + (size_t)mine * blk_bytes, (const char *)c->scratch[r] + (size_t)mine * blk_bytes,
-                           blk_bytes, hipMemcpyDeviceToDevice, (hipStream_t)qsim_stream(c->shard[r])) != hipSuccess)
+        if (ro.keep_own && hipMemcpyAsync(state[(size_t)r] + (size_t)ro.mine * blk_bytes, (const char *)c->scratch[r] + (size_t)ro.mine * blk_bytes,
+                                          blk_bytes, hipMemcpyDeviceToDevice, (hipStream_t)qsim_stream(c->shard[r])) != hipSuccess)
             return cfail(QSIM_ERR_DEVICE, "exchange copy failed");
+        const int rc = settle(c->shard[r], ro);
+        if (rc) return cfail(rc, "%s", qsim_last_error());
     }
     return QSIM_OK;
 }
@@ -511,6 +621,7 @@ static int exchange(qsim_cluster *c, const Step &st) {
     if (rc) return rc;
     c->exchanges++;
     c->exchange_bytes += (double)(((size_t)16 << c->m) >> k) * ((1 << k) - 1);
+    if (c->comms.empty() && !(c->same_device && k <= 3)) c->exchange_bytes_moved += (double)(((size_t)16 << c->m) >> k) * ((1 << k) - 1) * c->P;
     return QSIM_OK;
 }
 
@@ -532,8 +643,10 @@ extern "C" int qsim_cluster_run_circuit(qsim_cluster *c, const qsim_circuit *cir
     gates_of(circ, gates);
     Plan plan;
     if (!build_plan(c->n, c->p, gates, plan)) return cfail(QSIM_ERR_ARG, "planner made no progress");
-    for (const Step &st : plan.steps) {
-        const int rc = st.exchange ? exchange(c, st) : apply_local(c, st);
+    for (size_t i = 0; i < plan.steps.size(); i++) {
+        const Step &st = plan.steps[i];
+        const bool before_exchange = i + 1 < plan.steps.size() && plan.steps[i + 1].exchange;
+        const int rc = st.exchange ? exchange(c, st) : apply_local(c, st, !before_exchange);
         if (rc) return rc;
     }
     c->pos = plan.final_pos;
@@ -696,6 +809,17 @@ extern "C" int qsim_cluster_exchange_stats(const qsim_cluster *c, uint64_t *exch
     if (bytes_per_shard) *bytes_per_shard = c->exchange_bytes;
     return QSIM_OK;
 }
+extern "C" int qsim_cluster_exchange_bytes_moved(const qsim_cluster *c, double *bytes_all_shards) {
+    if (!c || !bytes_all_shards) return QSIM_ERR_ARG;
+    *bytes_all_shards = c->exchange_bytes_moved;
+    return QSIM_OK;
+}
+extern "C" int qsim_cluster_pack_counts(const qsim_cluster *c, uint64_t *fused, uint64_t *separate) {
+    if (!c) return QSIM_ERR_ARG;
+    if (fused) *fused = c->fused_packs;
+    if (separate) *separate = c->separate_packs;
+    return QSIM_OK;
+}
 
 // ---- the plan as an object (host only): what distributed.py's one-process-per-GPU driver executes -------------
 struct qsim_shard_plan {
@@ -736,6 +860,21 @@ extern "C" int qsim_shard_plan_step(const qsim_shard_plan *p, int step, int *kin
         if (shard_bits) shard_bits[i] = st.J[i];
         if (local_bits) local_bits[i] = st.Lsel[i];
     }
+    return QSIM_OK;
+}
+
+extern "C" int qsim_shard_plan_step_support(const qsim_shard_plan *p, int step, uint64_t *mixed_local, uint64_t *mixed_rank) {
+    if (!p || step < 0 || step >= (int)p->plan.steps.size() || !p->plan.steps[(size_t)step].exchange) return QSIM_ERR_ARG;
+    if (mixed_local) *mixed_local = p->plan.steps[(size_t)step].mixed_local;
+    if (mixed_rank) *mixed_rank = p->plan.steps[(size_t)step].mixed_rank;
+    return QSIM_OK;
+}
+
+extern "C" int qsim_shard_plan_exchange_roles(const qsim_shard_plan *p, int step, int shard, qsim_exchange_roles *out) {
+    if (!p || !out || step < 0 || step >= (int)p->plan.steps.size() || shard < 0 || shard >= p->P || !p->plan.steps[(size_t)step].exchange) return QSIM_ERR_ARG;
+    const Roles r = roles_of(shard, p->plan.m, p->plan.steps[(size_t)step]);
+    out->mine = r.mine; out->empty_before = r.empty_before; out->empty_after = r.empty_after; out->keep_own = r.keep_own;
+    out->send = r.send; out->recv = r.recv; out->unread = r.unread; out->new_support = r.new_support;
     return QSIM_OK;
 }
 
@@ -803,7 +942,7 @@ struct qsim_rank_comm {
     int world = 0, rank = 0, device = 0;
     void *scratch = nullptr;
     bool owns_scratch = false;
-    uint64_t exchanges = 0;
+    uint64_t exchanges = 0, fused_packs = 0, separate_packs = 0;
     double bytes_sent = 0, ms = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timing; // start/stop of exchanges not yet resolved
 };
@@ -842,6 +981,7 @@ extern "C" int qsim_rank_comm_create(qsim_rank_comm **out, qsim_state *shard, in
         if (hipMalloc(&c->scratch, (size_t)16 << qsim_num_qubits(shard)) != hipSuccess) { delete c; return cfail(QSIM_ERR_ALLOC, "Malloc error"); }
         c->owns_scratch = true;
     }
+    (void)qsim_set_spare_buffer(shard, c->scratch); // idle between exchanges: the second buffer of the shard's out-of-place passes
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
     const ncclResult_t nr = ncclCommInitRank(&c->comm, world, uid, rank);
@@ -854,17 +994,15 @@ extern "C" int qsim_rank_comm_create(qsim_rank_comm **out, qsim_state *shard, in
     return QSIM_OK;
 }
 
-// Swaps k rank-id bits (shard_bits, ascending) with k local bits (local_bits, ascending) of this rank's shard.
-extern "C" int qsim_rank_comm_exchange(qsim_rank_comm *c, const int *shard_bits, const int *local_bits, int k) {
-    if (!c || !shard_bits || !local_bits) return cfail(QSIM_ERR_ARG, "NULL argument");
+// Swaps k rank-id bits (st.J, ascending) with k local bits (st.Lsel, ascending) of this rank's shard; st.mixed_* say where the
+// register can be non-zero (all ones: anywhere), see roles_of.
+static int rank_exchange(qsim_rank_comm *c, const Step &st) {
+    const int k = (int)st.J.size();
     const int m = qsim_num_qubits(c->shard);
     if (k < 1 || k > m || (1 << k) > c->world) return cfail(QSIM_ERR_ARG, "exchange of %d qubits unsupported here", k);
-    const std::vector<int> J(shard_bits, shard_bits + k);
-    for (int j : J)
+    for (int j : st.J)
         if (j < 0 || (1 << j) >= c->world) return cfail(QSIM_ERR_ARG, "rank bit %d outside the world", j);
-    int mine;
-    std::vector<int> members;
-    peers_of(c->rank, J, mine, members);
+    const Roles ro = roles_of(c->rank, m, st);
     const size_t blk_bytes = ((size_t)16 << m) >> k;
     if (hipSetDevice(c->device) != hipSuccess) return cfail(QSIM_ERR_DEVICE, "hipSetDevice failed");
     hipStream_t stream = (hipStream_t)qsim_stream(c->shard);
@@ -874,31 +1012,60 @@ extern "C" int qsim_rank_comm_exchange(qsim_rank_comm *c, const int *shard_bits,
     const bool timed = qsim_get_option(c->shard, QSIM_OPT_PROFILE) != 0 && c->timing.size() < 4096;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) return cfail(QSIM_ERR_DEVICE, "event creation failed");
-    int rc = qsim_flush(c->shard); // everything queued so far belongs in front of the exchange
+    // Everything queued so far belongs in front of the exchange, and the last tile pass of it writes the state straight into
+    // the packed layout where it can (qsim_flush_pack): the exchange then costs no sweep of its own.  (The timing below
+    // therefore starts behind that pass: what it measures is the transfer, plus the pack kernel when one had to run.)
+    int rc, fused = 0;
+    if (ro.empty_before) rc = qsim_flush(c->shard);
+    else rc = qsim_flush_pack(c->shard, st.Lsel.data(), k, nullptr, 0, c->scratch, st.mixed_local, ro.unread, nullptr, &fused);
     if (rc) return cfail(rc, "%s", qsim_last_error());
+    if (!ro.empty_before) (fused ? c->fused_packs : c->separate_packs)++;
     if (timed) (void)hipEventRecord(e0, stream);
-    rc = qsim_pack_bits(c->shard, local_bits, k, c->scratch);
-    if (rc) return cfail(rc, "%s", qsim_last_error());
-    char *state = (char *)qsim_device_ptr(c->shard);
+    char *state = (char *)qsim_state_buffer(c->shard);
     const char *scr = (const char *)c->scratch;
-    ncclResult_t nr = ncclGroupStart();
-    for (int b = 0; b < (1 << k) && nr == ncclSuccess; b++) {
-        if (b == mine) continue;
-        nr = ncclSend(scr + (size_t)b * blk_bytes, blk_bytes / 8, ncclDouble, members[b], c->comm, stream);
-        if (nr == ncclSuccess) nr = ncclRecv(state + (size_t)b * blk_bytes, blk_bytes / 8, ncclDouble, members[b], c->comm, stream);
+    if (ro.send | ro.recv) {
+        ncclResult_t nr = ncclGroupStart();
+        for (int b = 0; b < (1 << k) && nr == ncclSuccess; b++) {
+            if (ro.send >> b & 1u) nr = ncclSend(scr + (size_t)b * blk_bytes, blk_bytes / 8, ncclDouble, ro.members[b], c->comm, stream);
+            if (nr == ncclSuccess && (ro.recv >> b & 1u)) nr = ncclRecv(state + (size_t)b * blk_bytes, blk_bytes / 8, ncclDouble, ro.members[b], c->comm, stream);
+        }
+        const ncclResult_t ne = ncclGroupEnd();
+        if (nr == ncclSuccess) nr = ne;
+        if (nr != ncclSuccess) return cfail(QSIM_ERR_DEVICE, "RCCL exchange failed: %s", ncclGetErrorString(nr));
     }
-    const ncclResult_t ne = ncclGroupEnd();
-    if (nr == ncclSuccess) nr = ne;
-    if (nr != ncclSuccess) return cfail(QSIM_ERR_DEVICE, "RCCL exchange failed: %s", ncclGetErrorString(nr));
-    if (hipMemcpyAsync(state + (size_t)mine * blk_bytes, scr + (size_t)mine * blk_bytes, blk_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+    if (ro.keep_own && hipMemcpyAsync(state + (size_t)ro.mine * blk_bytes, scr + (size_t)ro.mine * blk_bytes, blk_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess)
         return cfail(QSIM_ERR_DEVICE, "exchange copy failed");
+    rc = settle(c->shard, ro);
+    if (rc) return cfail(rc, "%s", qsim_last_error());
     if (timed) {
         (void)hipEventRecord(e1, stream);
         c->timing.emplace_back(e0, e1);
     }
     c->exchanges++;
-    c->bytes_sent += (double)blk_bytes * ((1 << k) - 1);
+    c->bytes_sent += (double)blk_bytes * __builtin_popcount(ro.send);
     return QSIM_OK;
+}
+
+extern "C" int qsim_rank_comm_exchange(qsim_rank_comm *c, const int *shard_bits, const int *local_bits, int k) {
+    if (!c || !shard_bits || !local_bits) return cfail(QSIM_ERR_ARG, "NULL argument");
+    if (k < 1 || k > 16) return cfail(QSIM_ERR_ARG, "exchange of %d qubits unsupported here", k);
+    Step st;
+    st.exchange = true;
+    st.J.assign(shard_bits, shard_bits + k);
+    st.Lsel.assign(local_bits, local_bits + k);
+    st.mixed_local = st.mixed_rank = ~0ULL; // nothing is known about the contents: every block travels
+    return rank_exchange(c, st);
+}
+
+// The exchange of one step of a plan, with what the plan knows about the state at that point: a run starts from |0...0>,
+// so early exchanges involve shards that hold nothing and blocks that are zero throughout (Step::mixed_*); those neither
+// travel nor get written, and the shard goes on visiting only the part of itself that can be non-zero.
+extern "C" int qsim_rank_comm_exchange_step(qsim_rank_comm *c, const qsim_shard_plan *p, int step) {
+    if (!c || !p || step < 0 || step >= (int)p->plan.steps.size()) return cfail(QSIM_ERR_ARG, "bad argument");
+    const Step &st = p->plan.steps[(size_t)step];
+    if (!st.exchange) return cfail(QSIM_ERR_ARG, "step %d is not an exchange", step);
+    if (p->P != c->world) return cfail(QSIM_ERR_ARG, "plan for %d shards, communicator of %d ranks", p->P, c->world);
+    return rank_exchange(c, st);
 }
 
 // Exchanges so far, bytes this rank sent, and the seconds its stream spent in them (pack + send/recv, HIP events on the
@@ -920,6 +1087,13 @@ extern "C" int qsim_rank_comm_stats(qsim_rank_comm *c, uint64_t *exchanges, doub
     if (bytes_sent) *bytes_sent = c->bytes_sent;
     if (seconds) *seconds = c->ms * 1e-3;
     if (reset) { c->exchanges = 0; c->bytes_sent = 0; c->ms = 0; }
+    return QSIM_OK;
+}
+
+extern "C" int qsim_rank_comm_pack_counts(const qsim_rank_comm *c, uint64_t *fused, uint64_t *separate) {
+    if (!c) return QSIM_ERR_ARG;
+    if (fused) *fused = c->fused_packs;
+    if (separate) *separate = c->separate_packs;
     return QSIM_OK;
 }
 

@@ -73,11 +73,31 @@ struct ProfEvent {
     int n_ops;
     uint64_t high_mask;
     uint64_t order_code; // tile passes: the high tile bits in tile-local order, 5 bits each, lowest first
+    double visited;      // tile passes: fraction of the register's tiles the pass works on (the state's support)
 };
-struct LaunchRec { int kclass, n_ops; uint64_t high_mask; double ms; uint64_t order_code; };
+struct LaunchRec { int kclass, n_ops; uint64_t high_mask; double ms; uint64_t order_code; double visited; };
+
+// Everything a schedule depends on: the options that shape it, the state's support, the QSIM_SCHED_* overrides and the
+// gates themselves.  A cached plan is only replayed for a queue whose identity EQUALS the one it was built from, field by
+// field and gate by gate; the 64-bit key merely finds the candidates (FNV-1a is not collision resistant, and "results
+// identical to the reference" must not rest on a hash).
+struct PlanIdentity {
+    int opts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t support = 0;
+    SchedEnv env;
+    std::vector<QueuedGate> gates;
+};
+static bool same_gates(const QueuedGate *a, const QueuedGate *b, size_t count) {
+    for (size_t i = 0; i < count; i++) {
+        if (a[i].kind != b[i].kind || a[i].q0 != b[i].q0 || a[i].q1 != b[i].q1) return false;
+        if (a[i].kind != QSIM_GATE_CX && memcmp(a[i].m, b[i].m, (a[i].kind == QSIM_GATE_U1 ? 4 : 16) * sizeof(cd)) != 0) return false;
+    }
+    return true;
+}
 
 struct CachedPlan {
     uint64_t key = 0, wisdom_epoch = 0, last_use = 0;
+    PlanIdentity id;
     std::vector<Pass> passes;
     std::vector<TileGeom> geoms;   // per pass; meaningful for tile passes: the geometry in the order it was launched with
     std::vector<size_t> op_first;  // per pass: index of its first TileOp in d_ops
@@ -132,6 +152,8 @@ struct qsim_state {
     std::vector<struct CachedPlan> plans;
     uint64_t plan_clock = 0;
     int plan_cache = 1;
+    long debug_plan_key = 0; // QSIM_OPT_DEBUG_PLAN_KEY: != 0 = every queue gets this key (forced collisions, for the tests of the identity check)
+    uint64_t plan_hits = 0, plan_key_collisions = 0; // replays; key matches whose identity differed
 };
 
 static constexpr size_t kOpsCap = 512;  // a pass holds <= tile_max_ops blocks; the ring wraps with a stream sync
@@ -205,6 +227,8 @@ extern "C" void *qsim_device_ptr(qsim_state *s) {
     return s->amps;
 }
 extern "C" void *qsim_stream(qsim_state *s) { return s ? (void *)s->stream : nullptr; }
+// The buffer itself, nothing launched and nothing written first: for a caller that is about to overwrite (part of) it.
+extern "C" void *qsim_state_buffer(qsim_state *s) { return s ? s->amps : nullptr; }
 
 extern "C" int qsim_set_option(qsim_state *s, int option, long value) {
     if (!s) return fail(QSIM_ERR_ARG, "NULL state");
@@ -256,6 +280,9 @@ extern "C" int qsim_set_option(qsim_state *s, int option, long value) {
     case QSIM_OPT_SPARSE_START:
         s->sparse_start = value != 0;
         break;
+    case QSIM_OPT_DEBUG_PLAN_KEY:
+        s->debug_plan_key = value;
+        break;
     case QSIM_OPT_PINGPONG:
         if (value < 0 || value > 2) return fail(QSIM_ERR_ARG, "pingpong must be 0 (never), 1 (auto) or 2 (always)");
         s->pingpong = (int)value;
@@ -290,6 +317,7 @@ extern "C" long qsim_get_option(const qsim_state *s, int option) {
     case QSIM_OPT_PLAN_CACHE: return s->plan_cache;
     case QSIM_OPT_PINGPONG: return s->pingpong;
     case QSIM_OPT_SPARSE_START: return s->sparse_start;
+    case QSIM_OPT_DEBUG_PLAN_KEY: return s->debug_plan_key;
     default: return -1;
     }
 }
@@ -312,7 +340,7 @@ static int resolve_events(qsim_state *s) {
     for (auto &pe : s->events) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) s->stats.k_ms[pe.kclass] += ms;
-        if (s->launch_log.size() < (1u << 20)) s->launch_log.push_back({pe.kclass, pe.n_ops, pe.high_mask, (double)ms, pe.order_code});
+        if (s->launch_log.size() < (1u << 20)) s->launch_log.push_back({pe.kclass, pe.n_ops, pe.high_mask, (double)ms, pe.order_code, pe.visited});
         s->event_pool.push_back(pe.start);
         s->event_pool.push_back(pe.stop);
     }
@@ -324,8 +352,9 @@ struct LaunchScope { // records a start/stop pair around one launch when profili
     qsim_state *s;
     ProfEvent pe{};
     bool on;
-    LaunchScope(qsim_state *st, int kclass, int n_ops = 1, uint64_t high_mask = 0, uint64_t order_code = 0) : s(st), on(st->profile != 0) {
+    LaunchScope(qsim_state *st, int kclass, int n_ops = 1, uint64_t high_mask = 0, uint64_t order_code = 0, double visited = 1.0) : s(st), on(st->profile != 0) {
         if (on) {
+            pe.visited = visited;
             pe.kclass = kclass;
             pe.n_ops = n_ops;
             pe.high_mask = high_mask;
@@ -389,6 +418,36 @@ extern "C" int qsim_reset_shard(qsim_state *s, int holds_index0) {
     s->zero_ket_pending = true;
     s->partial = false;
     s->support = 0;
+    return QSIM_OK;
+}
+
+// The caller filled the buffer itself (the receiving end of an exchange) and knows where the new contents can be non-zero:
+// every amplitude whose index has a bit outside `support` is zero BY DEFINITION from now on (its memory need not have been
+// written), exactly the situation after the first tile passes of a run (qsim_state::support).  Tile passes then visit only
+// that part; anything else that looks at the buffer gets the zeros written first.
+extern "C" int qsim_set_support(qsim_state *s, uint64_t support) {
+    if (!s) return fail(QSIM_ERR_ARG, "NULL state");
+    const int rc = qsim_flush(s);
+    if (rc) return rc;
+    const uint64_t nmask = s->n >= 64 ? ~0ULL : ((1ULL << s->n) - 1ULL);
+    s->zero_ket_pending = false;
+    s->support = support & nmask;
+    s->partial = s->support != nmask;
+    if (!s->sparse_start && s->partial) return materialize_zero_ket(s); // the option is off: keep the state dense
+    return QSIM_OK;
+}
+
+// What the buffer holds right now, without touching it: *support = index bits that may be 1 in a written, possibly non-zero
+// amplitude (all ones for a dense state); *kind = 0 written (inside the support), 1 a pending basis state amp0 * |0...0> that no
+// kernel has written yet (amp0 = 0: the all-zero vector of a shard that holds nothing).  Queued gates are launched first.
+extern "C" int qsim_get_support(qsim_state *s, uint64_t *support, int *kind, double *amp0) {
+    if (!s) return fail(QSIM_ERR_ARG, "NULL state");
+    const int rc = qsim_flush(s);
+    if (rc) return rc;
+    const uint64_t nmask = s->n >= 64 ? ~0ULL : ((1ULL << s->n) - 1ULL);
+    if (support) *support = s->zero_ket_pending ? 0 : s->partial ? (s->support & nmask) : nmask;
+    if (kind) *kind = s->zero_ket_pending ? 1 : 0;
+    if (amp0) *amp0 = s->zero_ket_pending ? s->zero_ket_amp : 0.0;
     return QSIM_OK;
 }
 
@@ -629,13 +688,33 @@ static void *spare_buffer(qsim_state *s) {
     return s->spare;
 }
 
+// The re-layout of an exchange done by the stores of the last tile pass in front of it (qsim_flush_pack; kernels_impl.inc PACK).
+struct PackJob {
+    PackMap map{};
+    int bits[3] = {0, 0, 0};
+    void *out = nullptr;    // where the caller wants the packed state (NULL: whichever of the state's two buffers it is not in)
+    uint32_t skip = 0;      // blocks nobody will read (only the separate pack kernel leaves them out)
+    uint64_t needed = ~0ULL; // source index bits that may be 1 where the receivers expect data
+    void *packed_at = nullptr; // set when a tile pass did the re-layout: the buffer that now holds the packed state
+};
+
 // Launches a tile pass whose TileOps are already on the device (no statistics, no profiling events).  oop: write the
-// state to the spare buffer and make that the state (the caller checked spare_buffer()).
-static int launch_tile_prepared(qsim_state *s, const TileGeom &geom, const TileOp *d, int need, bool from_zero_ket, bool oop = false, uint64_t zero_mask = 0) {
+// state to the spare buffer and make that the state (the caller checked spare_buffer()).  job: the pass writes the state,
+// re-laid-out, to job->out (or the buffer the state is not in) and records where.
+static int launch_tile_prepared(qsim_state *s, const TileGeom &geom, const TileOp *d, int need, bool from_zero_ket, bool oop = false, uint64_t zero_mask = 0,
+                                PackJob *job = nullptr) {
     LaunchCfg cfg{s->stream, s->grid_cap};
     const int threads = s->tile_threads; // 0: default for the tile size
     void *out = oop ? s->spare : s->amps;
     hipError_t e;
+    if (job) {
+        void *dst = job->out ? job->out : (s->spare && s->spare != s->amps ? s->spare : nullptr);
+        if (!dst || dst == s->amps) return fail(QSIM_ERR_ARG, "internal: no buffer for the re-layout");
+        e = launch_tile(cfg, s->amps, dst, s->f32, geom, d, need, threads, from_zero_ket, s->zero_ket_amp, false, zero_mask, &job->map);
+        if (e != hipSuccess) return fail(QSIM_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+        job->packed_at = dst;
+        return QSIM_OK;
+    }
     if (s->debug_skip_ops) {
         TileGeom bare = geom;
         bare.n_scale = 0;
@@ -650,7 +729,8 @@ static int launch_tile_prepared(qsim_state *s, const TileGeom &geom, const TileO
 
 // Prepares the blocks of a tile pass for the given bit order in the pinned ring, uploads and launches them; `capture`
 // (optional) receives a copy of the prepared TileOps for the plan cache.
-static int launch_tile_pass(qsim_state *s, const Pass &p, const TileGeom &geom, bool from_zero_ket, std::vector<TileOp> *capture = nullptr, bool oop = false, uint64_t zero_mask = 0) {
+static int launch_tile_pass(qsim_state *s, const Pass &p, const TileGeom &geom, bool from_zero_ket, std::vector<TileOp> *capture = nullptr, bool oop = false, uint64_t zero_mask = 0,
+                            PackJob *job = nullptr) {
     const size_t need = p.blocks.size();
     if (need > s->ops_cap) return fail(QSIM_ERR_ARG, "tile pass with %zu ops exceeds the op buffer", need);
     if (s->ops_used + need > s->ops_cap) { // ring is full: wait until earlier passes have read their ops
@@ -673,13 +753,13 @@ static int launch_tile_pass(qsim_state *s, const Pass &p, const TileGeom &geom, 
     TileOp *d = s->d_ops + s->ops_used;
     HIP_TRY(hipMemcpyAsync(d, h, need * sizeof(TileOp), hipMemcpyHostToDevice, s->stream));
     s->ops_used += need;
-    return launch_tile_prepared(s, geom, d, (int)need, from_zero_ket, oop, zero_mask);
+    return launch_tile_prepared(s, geom, d, (int)need, from_zero_ket, oop, zero_mask, job);
 }
 
 // cached_geom / cached_ops: replay of a cached plan (the tile pass's order and device-resident TileOps);
 // capture / geom_out: the first run of a plan records them.
 static int launch_pass(qsim_state *s, const Pass &p, const TileGeom *cached_geom = nullptr, const TileOp *cached_ops = nullptr,
-                       std::vector<TileOp> *capture = nullptr, TileGeom *geom_out = nullptr, bool oop = false) {
+                       std::vector<TileOp> *capture = nullptr, TileGeom *geom_out = nullptr, bool oop = false, PackJob *job = nullptr) {
     const bool from_zero_ket = s->zero_ket_pending && p.kclass == QSIM_K_TILE;
     if ((s->zero_ket_pending || s->partial) && p.kclass != QSIM_K_TILE) { // only tile passes work on a partially written state
         const int rc = materialize_zero_ket(s);
@@ -733,9 +813,9 @@ static int launch_pass(qsim_state *s, const Pass &p, const TileGeom *cached_geom
         if (s->sparse_start && from_zero_ket) zero_mask = nmask;
         else if (s->partial) zero_mask = nmask & ~s->support;
         visited = 1.0 / (double)(1ULL << __builtin_popcountll(zero_mask & ~tmask));
-        LaunchScope scope(s, p.kclass, (int)p.blocks.size(), hm, oc);
-        const int rc = cached_ops ? launch_tile_prepared(s, geom, cached_ops, (int)p.blocks.size(), from_zero_ket, oop, zero_mask)
-                                  : launch_tile_pass(s, p, geom, from_zero_ket, capture, oop, zero_mask);
+        LaunchScope scope(s, p.kclass, (int)p.blocks.size(), hm, oc, visited);
+        const int rc = cached_ops ? launch_tile_prepared(s, geom, cached_ops, (int)p.blocks.size(), from_zero_ket, oop, zero_mask, job)
+                                  : launch_tile_pass(s, p, geom, from_zero_ket, capture, oop, zero_mask, job);
         if (rc) return rc;
         if (zero_mask) {
             s->support = (from_zero_ket ? 0 : s->support) | tmask;
@@ -758,16 +838,29 @@ static uint64_t current_support(const qsim_state *s) {
     return s->partial ? s->support : ~0ULL;
 }
 
-// FNV-1a over the options that shape a plan, the state's support and every gate: names a schedule
-static uint64_t gates_key(const qsim_state *s, const QueuedGate *gates, size_t count, uint64_t support) {
+// The identity of a schedule (PlanIdentity) without the gates, and its 64-bit name: FNV-1a over the options that shape a
+// plan, the state's support, the QSIM_SCHED_* overrides and every gate.  The key only FINDS cached plans and scheduler
+// hints; a plan is replayed only after plan_matches() has compared the identity itself.
+static PlanIdentity plan_identity(const qsim_state *s, size_t count, uint64_t support) {
+    PlanIdentity id;
+    const int opts[8] = {s->n, s->f32 ? 1 : 0, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, (int)count};
+    memcpy(id.opts, opts, sizeof opts);
+    id.support = support; // the schedule depends on where the state is known to be zero
+    id.env = read_sched_env();
+    return id;
+}
+static uint64_t gates_key(const qsim_state *s, const PlanIdentity &id, const QueuedGate *gates, size_t count) {
+    if (s->debug_plan_key) return (uint64_t)s->debug_plan_key;
     uint64_t h = 0xcbf29ce484222325ULL;
     auto mix = [&](const void *p, size_t n) {
         const unsigned char *b = (const unsigned char *)p;
         for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ULL; }
     };
-    const int opts[8] = {s->n, s->f32 ? 1 : 0, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, (int)count};
-    mix(opts, sizeof opts);
-    mix(&support, sizeof support); // the schedule depends on where the state is known to be zero
+    mix(id.opts, sizeof id.opts);
+    mix(&id.support, sizeof id.support);
+    const int env_i[9] = {(int)id.env.set, id.env.lookahead, id.env.rollout, id.env.window, id.env.local_iters, id.env.objective, id.env.merge, id.env.merge_qubits, id.env.cap};
+    mix(env_i, sizeof env_i);
+    mix(&id.env.cheap_margin, sizeof id.env.cheap_margin);
     for (size_t i = 0; i < count; i++) {
         const QueuedGate &g = gates[i];
         const int hd[3] = {g.kind, g.q0, g.q1};
@@ -776,13 +869,19 @@ static uint64_t gates_key(const qsim_state *s, const QueuedGate *gates, size_t c
     }
     return h;
 }
-static uint64_t queue_key(const qsim_state *s) { return gates_key(s, s->queue.data(), s->queue.size(), current_support(s)); }
+static bool plan_matches(const PlanIdentity &have, const PlanIdentity &want, const QueuedGate *gates, size_t count) {
+    return memcmp(have.opts, want.opts, sizeof have.opts) == 0 && have.support == want.support && have.env == want.env &&
+           have.gates.size() == count && same_gates(have.gates.data(), gates, count);
+}
 
 // Scheduler variant per circuit, decided by the planning step (qsim_tune_circuit): key -> SchedConfig::commute.  Circuits
 // that were never planned use the default.
+// The table is found by key alone: a colliding circuit would be scheduled with another circuit's variant — a valid schedule
+// either way (every variant is; the results never depend on it).  Bounded: beyond kMaxSchedHints circuits it starts afresh.
 struct SchedHint { int commute; double cheap_margin; int lookahead; };
 static std::mutex g_hints_mu;
 static std::map<uint64_t, SchedHint> g_sched_hints;
+constexpr size_t kMaxSchedHints = 4096;
 static void apply_sched_hint(uint64_t key, SchedConfig &cfg) {
     std::lock_guard<std::mutex> lock(g_hints_mu);
     auto it = g_sched_hints.find(key);
@@ -796,30 +895,72 @@ static bool have_sched_hints() {
     return !g_sched_hints.empty();
 }
 
-extern "C" int qsim_flush(qsim_state *s) {
+// A tile pass can take the re-layout on board when the kernel has that variant for its shape (fp64, 2^12-amplitude tiles, 512
+// threads) and when what it writes covers what the receivers will look at: a pass over a partially written state only
+// visits the tiles inside (support | its own tile bits), so source indices outside that never reach the output — fine as
+// long as job->needed (where the receivers expect data) lies inside it; else the pack kernel does the job (it writes zeros).
+// support_before: where the state can be non-zero when the pass starts (current_support() once every earlier pass has been launched).
+static bool pass_can_pack(const qsim_state *s, const Pass &p, const TileGeom &geom, const PackJob *job, uint64_t support_before) {
+    if (p.kclass != QSIM_K_TILE || s->debug_skip_ops || s->debug_skip_mem || !launch_tile_can_pack(s->f32, geom, s->tile_threads)) return false;
+    const uint64_t nmask = s->n >= 64 ? ~0ULL : ((1ULL << s->n) - 1ULL);
+    uint64_t after = (1ULL << geom.low_bits) - 1ULL;
+    for (int j = 0; j < geom.n_high; j++) after |= 1ULL << geom.high[j];
+    after |= support_before;
+    return ((job->needed & nmask) & ~after) == 0;
+}
+static uint64_t current_support(const qsim_state *s);
+
+// job != NULL: if the LAST pass of the queue is a tile pass that can do it, that pass writes the state re-laid-out (job->packed_at
+// says where) and the state's own buffers are left holding stale data; otherwise everything runs as usual and job->packed_at
+// stays NULL (the caller then runs the pack kernel).
+static int flush_impl(qsim_state *s, PackJob *job) {
     if (!s) return fail(QSIM_ERR_ARG, "NULL state");
     if (s->queue.empty()) return QSIM_OK;
+    if (s->zero_ket_pending && s->zero_ket_amp == 0.0) { // the all-zero vector (a shard that holds nothing yet): every gate maps it to itself
+        s->queue.clear();
+        return QSIM_OK;
+    }
     if (s->tile_bits - s->tile_low_bits < 2 || s->tile_bits - s->tile_low_bits > kMaxTileHigh)
         return fail(QSIM_ERR_ARG, "tile_bits - tile_low_bits must be in 2..%d", kMaxTileHigh);
     HIP_TRY(hipSetDevice(s->device));
     constexpr size_t kMaxPlans = 8, kMaxCachedOps = 4096;
     const bool cacheable = s->plan_cache && s->fuse >= 3 && s->debug_tile_order == 0 && s->queue.size() >= 8;
     const bool hinted = s->fuse >= 3 && have_sched_hints();
-    const uint64_t key = (cacheable || hinted) ? queue_key(s) : 0;
+    PlanIdentity ident;
+    uint64_t key = 0;
+    if (cacheable || hinted) {
+        ident = plan_identity(s, s->queue.size(), current_support(s));
+        key = gates_key(s, ident, s->queue.data(), s->queue.size());
+    }
     const uint64_t epoch = g_wisdom_epoch.load();
     if (cacheable) {
         for (CachedPlan &pl : s->plans) {
             if (pl.key != key || pl.wisdom_epoch != epoch) continue;
+            if (!plan_matches(pl.id, ident, s->queue.data(), s->queue.size())) { s->plan_key_collisions++; continue; } // same name, other circuit
+            s->plan_hits++;
             pl.last_use = ++s->plan_clock;
             s->queue.clear();
             // out-of-place tile passes come in pairs (the state ends where it started): with an odd count the last one stays in place
             size_t tiles = 0, seen = 0;
             for (const Pass &p : pl.passes) tiles += p.kclass == QSIM_K_TILE;
+            bool fuse_pack = false;
+            if (job && !pl.passes.empty()) {
+                uint64_t sup = current_support(s); // ... as the last pass will find it
+                for (size_t i = 0; i + 1 < pl.passes.size(); i++) {
+                    if (pl.passes[i].kclass != QSIM_K_TILE) { sup = ~0ULL; break; }
+                    sup |= (1ULL << pl.geoms[i].low_bits) - 1ULL;
+                    for (int j = 0; j < pl.geoms[i].n_high; j++) sup |= 1ULL << pl.geoms[i].high[j];
+                }
+                fuse_pack = pass_can_pack(s, pl.passes.back(), pl.geoms.back(), job, sup);
+            }
+            if (fuse_pack) tiles--; // the last tile pass writes the re-layout: the ones before it bring the state home
             const bool pp = tiles >= 2 && spare_buffer(s) != nullptr;
             for (size_t i = 0; i < pl.passes.size(); i++) {
                 const Pass &p = pl.passes[i];
                 int rc;
-                if (p.kclass == QSIM_K_TILE) {
+                if (fuse_pack && i + 1 == pl.passes.size()) {
+                    rc = launch_pass(s, p, &pl.geoms[i], pl.d_ops + pl.op_first[i], nullptr, nullptr, false, job);
+                } else if (p.kclass == QSIM_K_TILE) {
                     seen++;
                     rc = launch_pass(s, p, &pl.geoms[i], pl.d_ops + pl.op_first[i], nullptr, nullptr, pp && !(seen == tiles && (tiles & 1)));
                 } else {
@@ -838,34 +979,70 @@ extern "C" int qsim_flush(qsim_state *s) {
         else if (g.kind == QSIM_GATE_CX) sched.add_cx(g.q0, g.q1);
         else sched.add_2q(g.m, g.q0, g.q1);
     }
-    s->queue.clear();
     int rc = QSIM_OK;
     CachedPlan fresh;
+    if (cacheable) { fresh.id = std::move(ident); fresh.id.gates = std::move(s->queue); } // the plan remembers what it was built from
+    s->queue.clear();
     std::vector<TileOp> host_ops;
-    auto launch = [&](Pass &&p, bool oop) {
+    auto launch = [&](Pass &&p, bool oop, PackJob *pj = nullptr) {
         if (rc != QSIM_OK) return;
-        if (!cacheable) { rc = launch_pass(s, p, nullptr, nullptr, nullptr, nullptr, oop); return; }
+        if (!cacheable) { rc = launch_pass(s, p, nullptr, nullptr, nullptr, nullptr, oop, pj); return; }
         TileGeom g = p.geom;
         fresh.op_first.push_back(host_ops.size());
-        rc = launch_pass(s, p, nullptr, nullptr, &host_ops, &g, oop);
+        rc = launch_pass(s, p, nullptr, nullptr, &host_ops, &g, oop, pj);
         fresh.geoms.push_back(g);
         fresh.passes.push_back(std::move(p));
     };
     // Passes are launched as soon as they are scheduled — the GPU works while later passes are planned — except that
-    // with two buffers the most recent tile pass (and whatever followed it) is held back until the next tile pass
-    // arrives: only then is it known not to be the last one, which must bring the state back to its own buffer.
+    // with two buffers (or a re-layout to do) the most recent tile pass and whatever followed it are held back until the
+    // next tile pass arrives: only then is it known not to be the last one.  The last one brings the state back to its own
+    // buffer — or, when it is the very last pass and a re-layout is asked for, writes the state re-laid-out (job); a tile
+    // pass that may turn out to be that one reads the state from its own buffer, so the one before it has to lead home,
+    // which is why, with a job, TWO tile passes are held back.
     void *const home = s->amps;
     int pp = -1; // second buffer available?  asked when the first tile pass arrives (a queue without tile passes allocates nothing)
-    std::vector<Pass> held; // a tile pass, then the non-tile passes scheduled after it
+    std::vector<Pass> held, held2; // a tile pass, then the non-tile passes scheduled after it; held2: the tile pass before that one (job only)
+    auto run_group = [&](std::vector<Pass> &grp, bool oop, PackJob *pj) {
+        for (size_t i = 0; i < grp.size(); i++) launch(std::move(grp[i]), i == 0 && oop, i == 0 ? pj : nullptr);
+        grp.clear();
+    };
     auto release = [&](bool last) {
-        for (size_t i = 0; i < held.size(); i++)
-            launch(std::move(held[i]), i == 0 && (!last || s->amps != home)); // the last tile pass: out of place only if that leads home
-        held.clear();
+        if (!job) { // the last tile pass: out of place only if that leads home
+            run_group(held, pp > 0 && (!last || s->amps != home), nullptr);
+            return;
+        }
+        if (!last) { // a newer tile pass exists: held2 is neither last nor second to last
+            run_group(held2, pp > 0, nullptr);
+            held2.swap(held);
+            return;
+        }
+        // the end of the queue: held2 (if any) is the second-to-last tile pass, held the last one
+        bool fuse_last = false;
+        if (held.size() == 1) { // ... and the very last pass
+            uint64_t sup = current_support(s);
+            if (!held2.empty()) { // not launched yet
+                if (held2.size() > 1) sup = ~0ULL;
+                sup |= (1ULL << held2[0].geom.low_bits) - 1ULL;
+                for (int j = 0; j < held2[0].geom.n_high; j++) sup |= 1ULL << held2[0].geom.high[j];
+            }
+            fuse_last = pass_can_pack(s, held[0], held[0].geom, job, sup);
+        }
+        if (fuse_last) {
+            run_group(held2, pp > 0 && s->amps != home, nullptr); // must lead home: the packing pass reads the state's own buffer
+            if (s->amps != home && rc == QSIM_OK) { // no second-to-last pass to bring it home (cannot happen: out-of-place passes before came in pairs)
+                rc = fail(QSIM_ERR_ARG, "internal: state not in its own buffer before the re-layout");
+                return;
+            }
+            run_group(held, false, job);
+        } else {
+            run_group(held2, pp > 0, nullptr);
+            run_group(held, pp > 0 && s->amps != home, nullptr);
+        }
     };
     sched.finish([&](Pass &&p) {
         if (rc != QSIM_OK) return;
         if (p.kclass == QSIM_K_TILE && pp < 0) pp = spare_buffer(s) != nullptr ? 1 : 0;
-        if (pp <= 0) { launch(std::move(p), false); return; }
+        if (pp <= 0 && !job) { launch(std::move(p), false); return; }
         if (p.kclass == QSIM_K_TILE) release(false);
         if (p.kclass == QSIM_K_TILE || !held.empty()) held.push_back(std::move(p));
         else launch(std::move(p), false);
@@ -887,7 +1064,7 @@ extern "C" int qsim_flush(qsim_state *s) {
     fresh.last_use = ++s->plan_clock;
     size_t slot = s->plans.size();
     for (size_t i = 0; i < s->plans.size(); i++) // a stale plan of the same queue (the geometry table changed) is replaced
-        if (s->plans[i].key == key) slot = i;
+        if (s->plans[i].key == key && plan_matches(s->plans[i].id, fresh.id, fresh.id.gates.data(), fresh.id.gates.size())) slot = i;
     if (slot == s->plans.size() && s->plans.size() >= kMaxPlans) {
         slot = 0;
         for (size_t i = 1; i < s->plans.size(); i++)
@@ -902,6 +1079,16 @@ extern "C" int qsim_flush(qsim_state *s) {
     } else {
         s->plans.push_back(std::move(fresh));
     }
+    return QSIM_OK;
+}
+
+extern "C" int qsim_flush(qsim_state *s) { return flush_impl(s, nullptr); }
+
+extern "C" int qsim_plan_cache_stats(const qsim_state *s, uint64_t *plans, uint64_t *replays, uint64_t *key_collisions) {
+    if (!s) return fail(QSIM_ERR_ARG, "NULL state");
+    if (plans) *plans = s->plans.size();
+    if (replays) *replays = s->plan_hits;
+    if (key_collisions) *key_collisions = s->plan_key_collisions;
     return QSIM_OK;
 }
 
@@ -1096,7 +1283,9 @@ extern "C" int qsim_gather_masked(qsim_state *s, uint64_t base, uint64_t lo_mask
     return QSIM_OK;
 }
 
-static int pack_common(qsim_state *s, const int *bits, int nbits, void *dst, void *const *blocks) {
+// keep_partial: a state that has only been written inside its support is packed as it is — amplitudes outside the support
+// are packed as zeros without being loaded (k_pack zero_mask) — instead of having the zeros written out first.
+static int pack_common(qsim_state *s, const int *bits, int nbits, void *dst, void *const *blocks, bool keep_partial, uint32_t skip_blocks) {
     if (!s || !bits || (!dst && !blocks)) return fail(QSIM_ERR_ARG, "NULL argument");
     if (nbits < 1 || nbits > (blocks ? 3 : 8) || nbits > s->n) return fail(QSIM_ERR_ARG, "pack: %d bits unsupported", nbits);
     for (int j = 0; j < nbits; j++)
@@ -1104,29 +1293,87 @@ static int pack_common(qsim_state *s, const int *bits, int nbits, void *dst, voi
             return fail(QSIM_ERR_ARG, "pack: bit positions must be ascending and inside the shard");
     const size_t blk = (s->amp_bytes() << s->n) >> nbits;
     for (int b = 0; b < (blocks ? 1 << nbits : 0); b++) {
+        if ((skip_blocks >> b) & 1u) continue;
         if (!blocks[b]) return fail(QSIM_ERR_ARG, "pack: destination block %d is NULL", b);
         const char *p = (const char *)blocks[b], *a = (const char *)s->amps;
         if (p < a + (s->amp_bytes() << s->n) && a < p + blk) return fail(QSIM_ERR_ARG, "pack: a destination block overlaps the state");
     }
     if (dst == s->amps) return fail(QSIM_ERR_ARG, "pack: dst must not alias the state");
     int rc = qsim_flush(s);
-    if (rc == QSIM_OK) rc = materialize_zero_ket(s);
+    const uint64_t nmask = s->n >= 64 ? ~0ULL : ((1ULL << s->n) - 1ULL);
+    const bool as_is = keep_partial && !s->zero_ket_pending && s->partial;
+    if (rc == QSIM_OK && !as_is) rc = materialize_zero_ket(s);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(s->device));
     LaunchCfg cfg{s->stream, s->grid_cap};
     hipError_t e;
     {
         LaunchScope scope(s, QSIM_K_PACK);
-        e = launch_pack(cfg, s->amps, dst, blocks, s->f32, s->n, bits, nbits);
+        e = launch_pack(cfg, s->amps, dst, blocks, s->f32, s->n, bits, nbits, skip_blocks, as_is ? nmask & ~s->support : 0);
     }
     if (e != hipSuccess) return fail(QSIM_ERR_DEVICE, "pack launch failed: %s", hipGetErrorString(e));
     account(s, QSIM_K_PACK, 2.0 * (double)s->amp_bytes() * (double)(1ULL << s->n));
     return QSIM_OK;
 }
 
-extern "C" int qsim_pack_bits(qsim_state *s, const int *bits, int nbits, void *dst) { return pack_common(s, bits, nbits, dst, nullptr); }
+extern "C" int qsim_pack_bits(qsim_state *s, const int *bits, int nbits, void *dst) { return pack_common(s, bits, nbits, dst, nullptr, false, 0); }
 extern "C" int qsim_pack_bits_to(qsim_state *s, const int *bits, int nbits, void *const *dst_blocks) {
-    return pack_common(s, bits, nbits, nullptr, dst_blocks);
+    return pack_common(s, bits, nbits, nullptr, dst_blocks, false, 0);
+}
+extern "C" int qsim_pack_bits_sparse(qsim_state *s, const int *bits, int nbits, void *dst, void *const *dst_blocks, uint32_t skip_blocks) {
+    return pack_common(s, bits, nbits, dst_blocks ? nullptr : dst, dst_blocks, true, skip_blocks);
+}
+
+// qsim_flush + the re-layout of qsim_pack_bits_sparse in one call, so that the LAST tile pass of the queue can do the
+// re-layout with its own stores (PackJob): no separate sweep over the state.  The output is one buffer in which source bit
+// bits[j] lands on index bit to_bits[j] (NULL: n - nbits + j, the block index on top of a shard-sized buffer), the other
+// bits close ranks below, and konst is ORed in (a cluster that keeps all its shards' buffers in one allocation addresses
+// "block b of member j" that way).  Afterwards the state's own buffer holds stale data: the caller hands it its new contents
+// (an exchange's receives, qsim_swap_buffer) and says what they are (qsim_set_support / qsim_reset_shard).
+extern "C" int qsim_flush_pack(qsim_state *s, const int *bits, int nbits, const int *to_bits, uint64_t konst, void *out, uint64_t needed, uint32_t skip_blocks,
+                               void **packed_at, int *fused) {
+    if (!s || !bits) return fail(QSIM_ERR_ARG, "NULL argument");
+    if (nbits < 1 || nbits > 3 || nbits > s->n) return fail(QSIM_ERR_ARG, "flush_pack: %d bits unsupported", nbits);
+    for (int j = 0; j < nbits; j++)
+        if (bits[j] < 0 || bits[j] >= s->n || (j && bits[j] <= bits[j - 1])) return fail(QSIM_ERR_ARG, "flush_pack: bit positions must be ascending and inside the shard");
+    if (s->f32) return fail(QSIM_ERR_ARG, "flush_pack: fp64 states only");
+    PackJob job;
+    job.out = out;
+    job.skip = skip_blocks;
+    job.needed = needed;
+    job.map.k = nbits;
+    job.map.konst = konst;
+    for (int j = 0; j < nbits; j++) {
+        job.bits[j] = job.map.sel[j] = bits[j];
+        job.map.to[j] = to_bits ? to_bits[j] : s->n - nbits + j;
+        if (job.map.to[j] < s->n - nbits || job.map.to[j] > 62) return fail(QSIM_ERR_ARG, "flush_pack: destination bit %d collides with the bits that stay", job.map.to[j]);
+    }
+    const uint64_t nmask = s->n >= 64 ? ~0ULL : ((1ULL << s->n) - 1ULL);
+    for (int i = 0; i <= nbits; i++) { // keep bits with i selected bits below them
+        const uint64_t lo = i == 0 ? 0 : ((2ULL << bits[i - 1]) - 1ULL), hi = i == nbits ? nmask : ((1ULL << bits[i]) - 1ULL);
+        job.map.seg[i] = hi & ~lo & nmask;
+    }
+    for (int i = nbits + 1; i < 4; i++) job.map.seg[i] = 0;
+    if (!out && !s->spare) return fail(QSIM_ERR_ARG, "flush_pack: no output buffer (lend one with qsim_set_spare_buffer)");
+    int rc = flush_impl(s, &job);
+    if (rc) return rc;
+    if (job.packed_at) {
+        if (packed_at) *packed_at = job.packed_at;
+        if (fused) *fused = 1;
+        return QSIM_OK;
+    }
+    char *dst = (char *)(out ? out : s->spare);
+    void *blocks[8];
+    for (int b = 0; b < (1 << nbits); b++) {
+        uint64_t at = konst;
+        for (int j = 0; j < nbits; j++) at |= (uint64_t)((b >> j) & 1) << job.map.to[j];
+        blocks[b] = dst + 16 * at;
+    }
+    rc = pack_common(s, bits, nbits, nullptr, blocks, true, skip_blocks);
+    if (rc) return rc;
+    if (packed_at) *packed_at = dst;
+    if (fused) *fused = 0;
+    return QSIM_OK;
 }
 
 // Hands the state a different amplitude buffer and returns the old one: the second half of an exchange whose pack kernels
@@ -1134,13 +1381,13 @@ extern "C" int qsim_pack_bits_to(qsim_state *s, const int *bits, int nbits, void
 // state's device; whoever holds a buffer when it is destroyed frees it, so ownership simply travels with the pointers.
 extern "C" int qsim_swap_buffer(qsim_state *s, void **buffer) {
     if (!s || !buffer || !*buffer) return fail(QSIM_ERR_ARG, "NULL argument");
-    if (!s->owns) return fail(QSIM_ERR_ARG, "swap_buffer: the state does not own its buffer (qsim_create_external)");
-    int rc = qsim_flush(s);
-    if (rc == QSIM_OK) rc = materialize_zero_ket(s);
+    const int rc = qsim_flush(s);
     if (rc) return rc;
     void *old = s->amps;
     s->amps = *buffer;
     *buffer = old;
+    s->zero_ket_pending = false; // the new buffer's contents ARE the state: taken as written everywhere unless the caller says
+    s->partial = false;          // otherwise (qsim_set_support, qsim_reset_shard)
     if (s->spare == s->amps && !s->owns_spare) s->spare = old; // a lent spare that just became the state: the old state takes its place
     return QSIM_OK;
 }
@@ -1196,6 +1443,14 @@ extern "C" int qsim_launch_log_order(qsim_state *s, long index, int *order, int 
     const int n = __builtin_popcountll(r.high_mask);
     for (int j = 0; j < n; j++) order[j] = (int)((r.order_code >> (5 * j)) & 31u);
     *count = r.kclass == QSIM_K_TILE ? n : 0;
+    return QSIM_OK;
+}
+
+extern "C" int qsim_launch_log_visited(qsim_state *s, long index, double *visited) {
+    if (!s || !visited) return QSIM_ERR_ARG;
+    if (resolve_events(s)) return QSIM_ERR_DEVICE;
+    if (index < 0 || index >= (long)s->launch_log.size()) return QSIM_ERR_ARG;
+    *visited = s->launch_log[index].visited;
     return QSIM_OK;
 }
 
@@ -1267,7 +1522,7 @@ static void choose_schedule(qsim_state *s, const qsim_circuit *c, const SchedCon
         const double *U = g.kind == QSIM_GATE_U1 ? c->mats2 + 8 * (long)g.mat : g.kind == QSIM_GATE_CX ? nullptr : c->mats4 + 32 * (long)g.mat;
         for (int k = 0; U && k < (g.kind == QSIM_GATE_U1 ? 4 : 16); k++) o.m[k] = cd(U[2 * k], U[2 * k + 1]);
     }
-    const uint64_t key = gates_key(s, q.data(), q.size(), scfg.initial_support);
+    const uint64_t key = gates_key(s, plan_identity(s, q.size(), scfg.initial_support), q.data(), q.size());
     // the variants: clusters may / may not overtake (commute), how eagerly passes inside the support are kept (cheap_margin),
     // one more pass of lookahead where the local search is on; the default comes first and wins ties
     std::vector<SchedHint> variants;
@@ -1293,7 +1548,11 @@ static void choose_schedule(qsim_state *s, const qsim_circuit *c, const SchedCon
         const SchedHint dflt{scfg.commute, scfg.cheap_margin, scfg.lookahead};
         const SchedHint before = it == g_sched_hints.end() ? dflt : it->second;
         const SchedHint now = variants[best];
-        if (best == 0) g_sched_hints.erase(key); else g_sched_hints[key] = now;
+        if (best == 0) g_sched_hints.erase(key);
+        else {
+            if (g_sched_hints.size() >= kMaxSchedHints && it == g_sched_hints.end()) g_sched_hints.clear();
+            g_sched_hints[key] = now;
+        }
         if (before.commute != now.commute || before.cheap_margin != now.cheap_margin || before.lookahead != now.lookahead)
             g_wisdom_epoch++; // cached plans of this circuit were scheduled another way
     }

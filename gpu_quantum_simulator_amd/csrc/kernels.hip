@@ -64,15 +64,16 @@ hipError_t launch_diag1_full(const LaunchCfg &cfg, void *v, bool f32, int n, int
 hipError_t launch_cx(const LaunchCfg &cfg, void *v, bool f32, int n, int control, int target) { return QSIM_DISPATCH(launch_cx(cfg, v, n, control, target)); }
 hipError_t launch_gate2(const LaunchCfg &cfg, void *v, bool f32, int n, int q_hi, int q_lo, const M4 &U) { return QSIM_DISPATCH(launch_gate2(cfg, v, n, q_hi, q_lo, U)); }
 hipError_t launch_tile(const LaunchCfg &cfg, void *v, void *vout, bool f32, const TileGeom &g, const TileOp *d_ops, int n_ops, int threads, bool from_zero_ket,
-                       double amp0, bool nomem, uint64_t zero_mask) {
-    return QSIM_DISPATCH(launch_tile(cfg, v, vout, g, d_ops, n_ops, threads, from_zero_ket, amp0, nomem, zero_mask));
+                       double amp0, bool nomem, uint64_t zero_mask, const PackMap *pack) {
+    return QSIM_DISPATCH(launch_tile(cfg, v, vout, g, d_ops, n_ops, threads, from_zero_ket, amp0, nomem, zero_mask, pack));
 }
+bool launch_tile_can_pack(bool f32, const TileGeom &g, int threads) { return QSIM_DISPATCH(launch_tile_can_pack(g, threads)); }
 hipError_t launch_norm2(const LaunchCfg &cfg, const void *v, bool f32, int n, double *d_out) { return QSIM_DISPATCH(launch_norm2(cfg, v, n, d_out)); }
 hipError_t launch_block_prob(const LaunchCfg &cfg, const void *v, bool f32, int n, int block_bits, double *d_out) {
     return QSIM_DISPATCH(launch_block_prob(cfg, v, n, block_bits, d_out));
 }
-hipError_t launch_pack(const LaunchCfg &cfg, const void *in, void *out, void *const *blocks, bool f32, int n, const int *bits, int p) {
-    return QSIM_DISPATCH(launch_pack(cfg, in, out, blocks, n, bits, p));
+hipError_t launch_pack(const LaunchCfg &cfg, const void *in, void *out, void *const *blocks, bool f32, int n, const int *bits, int p, uint32_t skip_blocks, uint64_t zero_mask) {
+    return QSIM_DISPATCH(launch_pack(cfg, in, out, blocks, n, bits, p, skip_blocks, zero_mask));
 }
 hipError_t launch_block_prob_masked(const LaunchCfg &cfg, const void *v, bool f32, uint64_t hi_mask, uint64_t lo_mask, double *d_out) {
     return QSIM_DISPATCH(launch_block_prob_masked(cfg, v, hi_mask, lo_mask, d_out));

@@ -77,6 +77,18 @@ struct TileGeom {
     int32_t n_scale;            // leading entries of the pass's op list that are TOP_SCALE factors, not blocks
 };
 
+// Output permutation of a tile pass that also does the re-layout of an exchange (the pack): the amplitude read at index x is
+// written at index  perm(x) = sum_i ((x & seg[i]) >> i)  |  sum_j (bit sel[j] of x) << to[j]  |  konst  of the OUTPUT buffer.
+// sel[0..k) are the k <= 3 index bits that leave (ascending); the bits between them (seg[i]: the ones with i selected bits
+// below them) close ranks.  One scratch buffer per shard: to[j] = n - k + j (the block index on top), konst = 0.  All shards
+// of a cluster in one allocation: to[j] = the shard-id bit that takes the qubit, konst = the rest of the destination.
+struct PackMap {
+    uint64_t seg[4];
+    uint64_t konst;
+    int32_t sel[3], to[3];
+    int32_t k; // 0: no re-layout
+};
+
 struct LaunchCfg {
     hipStream_t stream;
     int grid_cap; // 0 = one workgroup per work tile
@@ -94,8 +106,10 @@ hipError_t launch_gate2(const LaunchCfg &cfg, void *v, bool f32, int n, int q_hi
 // zero_mask: index bits the state is known to be |0> in — tiles with such a bit in their base index are skipped, slots
 // with one inside a tile are staged in as zero (their memory may never have been written)
 // vout: where the pass writes the state — v itself (in place) or a second buffer of the same size
+// pack (fp64, the default tile shape only — launch_tile_can_pack): vout is the output buffer of the re-layout, written at perm(index)
 hipError_t launch_tile(const LaunchCfg &cfg, void *v, void *vout, bool f32, const TileGeom &g, const TileOp *d_ops, int n_ops, int threads,
-                       bool from_zero_ket, double amp0, bool nomem = false, uint64_t zero_mask = 0);
+                       bool from_zero_ket, double amp0, bool nomem = false, uint64_t zero_mask = 0, const PackMap *pack = nullptr);
+bool launch_tile_can_pack(bool f32, const TileGeom &g, int threads);
 // zeroes the amplitudes whose index has a bit of zero_mask set (the part of a state the tile passes have not written yet)
 hipError_t launch_zero_outside(const LaunchCfg &cfg, void *v, bool f32, int n, uint64_t zero_mask);
 hipError_t launch_norm2(const LaunchCfg &cfg, const void *v, bool f32, int n, double *d_out /* zeroed */);
@@ -108,7 +122,10 @@ hipError_t launch_gather_masked(const LaunchCfg &cfg, const void *v, bool f32, u
 // out[dst] = in[src]: dst = (block << (n-p)) | rest, where block = the p bits of src at positions
 // `bits` (ascending) and rest = the remaining n-p bits of src in order.
 // `blocks` != NULL (p <= 3): block b goes to blocks[b] (2^(n-p) amplitudes each) instead of out + b * 2^(n-p).
-hipError_t launch_pack(const LaunchCfg &cfg, const void *in, void *out, void *const *blocks, bool f32, int n, const int *bits, int p);
+// skip_blocks bit b: block b is not written (nobody will read it; with `blocks`, blocks[b] may then be NULL)
+// zero_mask: index bits the source is zero in by definition (a partially written state): such amplitudes are packed as zeros, not loaded
+hipError_t launch_pack(const LaunchCfg &cfg, const void *in, void *out, void *const *blocks, bool f32, int n, const int *bits, int p, uint32_t skip_blocks = 0,
+                       uint64_t zero_mask = 0);
 
 } // namespace qsim
 #endif

@@ -99,19 +99,41 @@ void Scheduler::cx4(bool control_is_hi, cd out[16]) {
 // product of diagonal matrices has an exact-zero factor.
 
 // The QSIM_SCHED_* variables override the search parameters for experiments (tools/); they are not
-// part of the API and change the pass count, never the result.
-Scheduler::Scheduler(const SchedConfig &cfg) : cfg_(cfg), open_(cfg.n > 0 ? cfg.n : 0, -1) {
-    if (const char *v = getenv("QSIM_SCHED_LOOKAHEAD")) cfg_.lookahead = atoi(v);
-    if (const char *v = getenv("QSIM_SCHED_ROLLOUT")) cfg_.rollout = atoi(v);
-    if (const char *v = getenv("QSIM_SCHED_WINDOW")) cfg_.window = atoi(v);
-    if (const char *v = getenv("QSIM_SCHED_LOCAL")) cfg_.local_iters = atoi(v);
-    if (const char *v = getenv("QSIM_SCHED_OBJ")) cfg_.objective = atoi(v);
-    if (const char *v = getenv("QSIM_SCHED_MERGE")) cfg_.merge = atoi(v);
-    if (const char *v = getenv("QSIM_SCHED_MERGEQ")) cfg_.merge_qubits = atoi(v);
-    if (const char *v = getenv("QSIM_SCHED_CHEAP")) cfg_.cheap_margin = atof(v);
-    if (getenv("QSIM_SCHED_NOCOMMUTE")) cfg_.commute = 0;
-    if (const char *v = getenv("QSIM_SCHED_CAP")) { cfg_.tile_max_ops = atoi(v); cfg_.tail_max_ops = 0; }
+// part of the API and change the pass count, never the result (scheduler.h SchedEnv).
+SchedEnv read_sched_env() {
+    SchedEnv e;
+    int bit = 0;
+    auto geti = [&](const char *name, int &dst) { if (const char *v = getenv(name)) { dst = atoi(v); e.set |= 1u << bit; } bit++; };
+    geti("QSIM_SCHED_LOOKAHEAD", e.lookahead);
+    geti("QSIM_SCHED_ROLLOUT", e.rollout);
+    geti("QSIM_SCHED_WINDOW", e.window);
+    geti("QSIM_SCHED_LOCAL", e.local_iters);
+    geti("QSIM_SCHED_OBJ", e.objective);
+    geti("QSIM_SCHED_MERGE", e.merge);
+    geti("QSIM_SCHED_MERGEQ", e.merge_qubits);
+    geti("QSIM_SCHED_CAP", e.cap);
+    if (const char *v = getenv("QSIM_SCHED_CHEAP")) { e.cheap_margin = atof(v); e.set |= 1u << bit; }
+    bit++;
+    if (getenv("QSIM_SCHED_NOCOMMUTE")) e.set |= 1u << bit;
+    return e;
 }
+
+void apply_sched_env(const SchedEnv &e, SchedConfig &cfg) {
+    int bit = 0;
+    auto on = [&]() { return (e.set >> bit++) & 1u; };
+    if (on()) cfg.lookahead = e.lookahead;
+    if (on()) cfg.rollout = e.rollout;
+    if (on()) cfg.window = e.window;
+    if (on()) cfg.local_iters = e.local_iters;
+    if (on()) cfg.objective = e.objective;
+    if (on()) cfg.merge = e.merge;
+    if (on()) cfg.merge_qubits = e.merge_qubits;
+    if (on()) { cfg.tile_max_ops = e.cap; cfg.tail_max_ops = 0; }
+    if (on()) cfg.cheap_margin = e.cheap_margin;
+    if (on()) cfg.commute = 0;
+}
+
+Scheduler::Scheduler(const SchedConfig &cfg) : cfg_(cfg), open_(cfg.n > 0 ? cfg.n : 0, -1) { apply_sched_env(read_sched_env(), cfg_); }
 
 void Scheduler::close(int idx) {
     if (idx < 0) return;

@@ -140,6 +140,22 @@ struct SchedConfig {
     int commute = 1;
 };
 
+// The QSIM_SCHED_* environment variables override the search parameters for experiments (tools/).
+// They are not part of the API and change the pass count, never the result — but they DO shape the schedule, so the
+// engine folds this record into the identity of a cached plan (a plan built under one setting is never replayed under
+// another).  `set` has one bit per variable that is present.
+struct SchedEnv {
+    uint32_t set = 0;
+    int lookahead = 0, rollout = 0, window = 0, local_iters = 0, objective = 0, merge = 0, merge_qubits = 0, cap = 0;
+    double cheap_margin = 0;
+    bool operator==(const SchedEnv &o) const {
+        return set == o.set && lookahead == o.lookahead && rollout == o.rollout && window == o.window && local_iters == o.local_iters &&
+               objective == o.objective && merge == o.merge && merge_qubits == o.merge_qubits && cap == o.cap && cheap_margin == o.cheap_margin;
+    }
+};
+SchedEnv read_sched_env();                      // the environment as it is now
+void apply_sched_env(const SchedEnv &e, SchedConfig &cfg);
+
 class Scheduler {
   public:
     explicit Scheduler(const SchedConfig &cfg);

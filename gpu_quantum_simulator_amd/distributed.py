@@ -159,9 +159,12 @@ class HipShard:
     def reset(self, holds_index0: bool):
         self.sim.reset(holds_index0)
 
-    def apply_local(self, key: int):
+    def apply_local(self, key: int, flush: bool = True):
+        """flush=False: leave the step's gates queued — the exchange that follows launches them itself, so that the last
+        tile pass can write the state straight into the packed layout (qsim_flush_pack)."""
         self._plan.apply_local(key, self.sim)
-        self.sim.flush()
+        if flush:
+            self.sim.flush()
 
     def pack(self, Lsel):
         self.sim.pack_bits(list(Lsel), self.scratch.data_ptr())
@@ -307,9 +310,13 @@ class ShardedSimulator:
         self.shard.reset(self.rank == 0)
         for i, st in enumerate(self.plan.steps):
             if st[0] == "local":
-                self.shard.apply_local(i)
+                before_exchange = i + 1 < len(self.plan.steps) and self.plan.steps[i + 1][0] == "exchange"
+                if before_exchange and self.exchange_backend == "rccl-native":
+                    self.shard.apply_local(i, flush=False)
+                else:
+                    self.shard.apply_local(i)
             elif self.exchange_backend == "rccl-native":
-                self.shard.comm.exchange(st[1], st[2])  # pack + one ncclGroup on the engine's stream; nothing waits here
+                self.shard.comm.exchange_step(self.plan.handle, i)  # pack + one ncclGroup on the engine's stream; nothing waits here
             else:
                 t0 = time.perf_counter()
                 self._exchange(st[1], st[2])

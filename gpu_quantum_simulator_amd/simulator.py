@@ -163,7 +163,7 @@ class Simulator:
                  "grid_cap": _lib.OPT_GRID_CAP, "tile_threads": _lib.OPT_TILE_THREADS,
                  "tile_pad_from": _lib.OPT_TILE_PAD_FROM, "debug_skip_ops": _lib.OPT_DEBUG_SKIP_OPS,
                  "debug_skip_mem": _lib.OPT_DEBUG_SKIP_MEM, "debug_tile_order": _lib.OPT_DEBUG_TILE_ORDER, "plan_cache": _lib.OPT_PLAN_CACHE,
-                 "pingpong": _lib.OPT_PINGPONG, "sparse_start": _lib.OPT_SPARSE_START}
+                 "pingpong": _lib.OPT_PINGPONG, "sparse_start": _lib.OPT_SPARSE_START, "debug_plan_key": _lib.OPT_DEBUG_PLAN_KEY}
         # tile_low_bits first when shrinking, tile_bits first when growing: keep every intermediate valid
         for key in sorted(options, key=lambda k: k != "tile_low_bits"):
             self.set_option(names[key], options[key])
@@ -208,6 +208,13 @@ class Simulator:
     def flush(self) -> None:
         check(_lib.load().qsim_flush(self._h))
 
+    def plan_cache_stats(self) -> dict:
+        """qsim_plan_cache_stats: plans held, replays, key matches rejected by the identity check."""
+        from ctypes import c_uint64
+        a, b, c = c_uint64(), c_uint64(), c_uint64()
+        check(_lib.load().qsim_plan_cache_stats(self._h, byref(a), byref(b), byref(c)))
+        return {"plans": int(a.value), "replays": int(b.value), "key_collisions": int(c.value)}
+
     def choose_schedule(self, circuit: Circuit) -> None:
         """qsim_choose_schedule: the schedule choice of the planning step alone (no timing)."""
         check(_lib.load().qsim_choose_schedule(self._h, circuit._h))
@@ -220,11 +227,33 @@ class Simulator:
         check(_lib.load().qsim_tune_circuit_from(self._h, circuit._h, max_candidates, budget_ms, byref(rep), 1 if dense_start else 0))
         return rep.as_dict()
 
+    def flush_pack(self, bits: Sequence[int], out_ptr: Optional[int] = None, to_bits: Optional[Sequence[int]] = None, konst: int = 0,
+                   needed: int = (1 << 64) - 1, skip_blocks: int = 0):
+        """qsim_flush_pack: everything queued is launched and the state ends re-laid-out in `out_ptr` (default: the spare
+        buffer); returns (buffer holding the packed state, whether the last tile pass did the re-layout)."""
+        k = len(bits)
+        arr = (c_int * k)(*bits)
+        to = (c_int * k)(*to_bits) if to_bits is not None else None
+        at, fused = c_void_p(), c_int()
+        check(_lib.load().qsim_flush_pack(self._h, arr, k, to, konst, c_void_p(out_ptr or 0), needed, skip_blocks, byref(at), byref(fused)))
+        return int(at.value or 0), bool(fused.value)
+
     def pack_bits_to(self, bits: Sequence[int], dst_ptrs: Sequence[int]) -> None:
         """qsim_pack_bits_to: block b of the packed layout goes to dst_ptrs[b]."""
         arr = (c_int * len(bits))(*bits)
         ptrs = (c_void_p * len(dst_ptrs))(*dst_ptrs)
         check(_lib.load().qsim_pack_bits_to(self._h, arr, len(bits), ptrs))
+
+    def set_support(self, support: int) -> None:
+        """qsim_set_support: amplitudes whose index has a bit outside `support` are zero by definition from now on."""
+        check(_lib.load().qsim_set_support(self._h, support))
+
+    def get_support(self):
+        """(support mask, pending basis state?, its amplitude) — qsim_get_support."""
+        from ctypes import c_uint64
+        m, k, a = c_uint64(), c_int(), c_double()
+        check(_lib.load().qsim_get_support(self._h, byref(m), byref(k), byref(a)))
+        return int(m.value), bool(k.value), float(a.value)
 
     def set_spare_buffer(self, ptr: Optional[int]):
         """qsim_set_spare_buffer: lends the state a second device buffer for out-of-place tile passes (None takes it back)."""
@@ -375,6 +404,19 @@ class Cluster:
         _lib.load().qsim_cluster_exchange_stats(self._h, byref(n), byref(b))
         return int(n.value), float(b.value)
 
+    def pack_counts(self):
+        """(re-layouts done by the last tile pass in front of an exchange, by the separate pack kernel) per shard and exchange."""
+        from ctypes import c_uint64
+        a, b = c_uint64(), c_uint64()
+        _lib.load().qsim_cluster_pack_counts(self._h, byref(a), byref(b))
+        return int(a.value), int(b.value)
+
+    def exchange_bytes_moved(self) -> float:
+        """Bytes all shards together really sent (blocks of / for shards that hold nothing stay home)."""
+        b = c_double()
+        _lib.load().qsim_cluster_exchange_bytes_moved(self._h, byref(b))
+        return float(b.value)
+
     @property
     def exchange_mode(self) -> str:
         """"rccl" | "direct" | "copies" | "none" (qsim_cluster_exchange_mode)."""
@@ -440,6 +482,19 @@ class ShardPlanHandle:
         if rc:
             raise _lib.QsimError(rc, (_lib.load().qsim_cluster_error() or b"").decode())
 
+    def step_support(self, i: int):
+        """(mixed_local, mixed_rank) of an exchange step: where the register can be non-zero just before it."""
+        from ctypes import c_uint64
+        a, b = c_uint64(), c_uint64()
+        check(_lib.load().qsim_shard_plan_step_support(self._h, i, byref(a), byref(b)))
+        return int(a.value), int(b.value)
+
+    def exchange_roles(self, i: int, shard: int) -> dict:
+        """qsim_shard_plan_exchange_roles: what one shard sends, receives and holds afterwards in the exchange of step i."""
+        r = _lib.QsimExchangeRoles()
+        check(_lib.load().qsim_shard_plan_exchange_roles(self._h, i, shard, byref(r)))
+        return r.as_dict()
+
     def final_pos(self) -> list:
         pos = (c_int * self.num_qubits)()
         check(_lib.load().qsim_shard_plan_final_pos(self._h, pos))
@@ -498,11 +553,24 @@ class RankComm:
         if rc:
             raise _lib.QsimError(rc, (_lib.load().qsim_cluster_error() or b"").decode())
 
+    def exchange_step(self, plan: "ShardPlanHandle", step: int) -> None:
+        """qsim_rank_comm_exchange_step: the exchange of one plan step, leaving out what the plan knows to be zero."""
+        rc = _lib.load().qsim_rank_comm_exchange_step(self._h, plan._h, step)
+        if rc:
+            raise _lib.QsimError(rc, (_lib.load().qsim_cluster_error() or b"").decode())
+
     def loopback(self, count: int) -> None:
         """`count` doubles of the shard through ncclSend -> ncclRecv to this same rank (qsim_rank_comm_loopback)."""
         rc = _lib.load().qsim_rank_comm_loopback(self._h, count)
         if rc:
             raise _lib.QsimError(rc, (_lib.load().qsim_cluster_error() or b"").decode())
+
+    def pack_counts(self):
+        """(re-layouts done by the last tile pass in front of an exchange, by the separate pack kernel)."""
+        from ctypes import c_uint64
+        a, b = c_uint64(), c_uint64()
+        _lib.load().qsim_rank_comm_pack_counts(self._h, byref(a), byref(b))
+        return int(a.value), int(b.value)
 
     def stats(self, reset: bool = False):
         """(exchanges, bytes sent by this rank, seconds its stream spent in exchanges)."""

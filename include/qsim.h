@@ -71,6 +71,9 @@ enum {
                                 * passes only visit the rest: the first pass of a circuit writes one tile, the second a few hundred,
                                 * the full sweeps start when every qubit has been inside a tile (memory outside that support is
                                 * written as zeros the moment anything else looks at the buffer).  0 = every pass sweeps the register */
+    QSIM_OPT_DEBUG_PLAN_KEY = 16,/* test aid, default 0: k != 0 = every flushed queue gets the plan-cache key k, i.e. all circuits collide;
+                                  * results must not change — a cached plan is only replayed after its gate list, options and
+                                  * support have been compared with the queue's (qsim_plan_cache_stats counts the collisions) */
     QSIM_OPT_DEBUG_TILE_ORDER = 12,/* measurement aid, default 0: k > 0 = every tile pass walks its high tile bits in a pseudo-random
                                   * order seeded by k (results are unchanged: the order only decides which bits lanes, waves and
                                   * registers walk) */
@@ -138,6 +141,9 @@ int qsim_apply_cx(qsim_state *s, int control, int target);
 /* kernel_gate_4 (quantum_simulator_4x4.cu:109-146): U is 16 complex, row/col index = (bit q_hi, bit q_lo). */
 int qsim_apply_2q(qsim_state *s, const double *U, int q_hi, int q_lo);
 int qsim_flush(qsim_state *s); /* schedule + launch everything queued; returns without waiting */
+/* QSIM_OPT_PLAN_CACHE bookkeeping: plans held, flushes served by replaying one, and 64-bit key matches that were REJECTED because
+ * the cached plan's gate list / options / support differed from the queue's (the key only finds candidates). */
+int qsim_plan_cache_stats(const qsim_state *s, uint64_t *plans, uint64_t *replays, uint64_t *key_collisions);
 int qsim_sync(qsim_state *s);  /* flush, then wait for the stream */
 
 /* ---- amplitudes in / out (the reference's final cudaMemcpy D2H, quantum_simulator_naive.cu:193-194) -- */
@@ -209,6 +215,32 @@ int qsim_pack_bits(qsim_state *s, const int *bits, int nbits, void *dst_device);
  * spare buffer (now holding the shard's new contents) the state and hands back the old one. */
 int qsim_pack_bits_to(qsim_state *s, const int *bits, int nbits, void *const *dst_blocks);
 int qsim_swap_buffer(qsim_state *s, void **buffer_device);
+/* The receiving side of an exchange knows where its new contents can be non-zero (a run starts from |0...0>, and a qubit
+ * stays |0> until a gate mixes it): qsim_set_support declares every amplitude whose index has a bit outside `support` zero BY
+ * DEFINITION — that memory need not have been written — which is the state the first tile passes of a run leave behind
+ * (QSIM_OPT_SPARSE_START): later tile passes visit only that part, anything else gets the zeros written out first.
+ * qsim_get_support reports the current situation without touching the buffer: *support = index bits that may be 1 (all
+ * ones: dense), *kind = 1 while the state is a basis state amp0 * |0...0> that no kernel has written yet (amp0 = 0: the
+ * all-zero vector of a shard that holds nothing — gates applied to it are dropped), else 0.
+ * qsim_pack_bits_sparse is qsim_pack_bits / qsim_pack_bits_to (dst_blocks != NULL) without the detour of writing the zeros out
+ * first: amplitudes outside the state's support are packed as zeros straight away (never loaded), and the blocks in skip_blocks
+ * (bit b: block b; its destination may be NULL) are not written at all — nobody will look at them.
+ * qsim_state_buffer: the amplitude buffer as is — nothing launched, nothing written (for a caller about to overwrite it). */
+int qsim_set_support(qsim_state *s, uint64_t support);
+int qsim_get_support(qsim_state *s, uint64_t *support, int *kind, double *amp0);
+int qsim_pack_bits_sparse(qsim_state *s, const int *bits, int nbits, void *dst_device, void *const *dst_blocks, uint32_t skip_blocks);
+void *qsim_state_buffer(qsim_state *s);
+/* qsim_flush and the re-layout of qsim_pack_bits_sparse in ONE call: when the last pass of the queue is a tile pass of the
+ * default shape, its stores write the state re-laid-out (*fused = 1) and the exchange costs no sweep of its own; otherwise the
+ * passes run as usual and the pack kernel follows (*fused = 0).  The output is one buffer (`out`; NULL: the state's spare
+ * buffer) in which source index bit bits[j] lands on bit to_bits[j] (NULL: num_q - nbits + j, i.e. the block index on top of
+ * a shard-sized buffer), the other bits close ranks below, and konst is ORed into the index (a cluster that keeps every
+ * shard's buffer in one allocation addresses "block b of member j" that way).  needed: source index bits that may be 1 where
+ * the receivers expect data (a fusing pass over a partially written state only writes inside its support; if that does not
+ * cover `needed` the pack kernel, which writes the zeros, is used).  Afterwards the state's own buffer holds stale data:
+ * hand it its new contents (receives, qsim_swap_buffer) and say what they are (qsim_set_support / qsim_reset_shard). */
+int qsim_flush_pack(qsim_state *s, const int *bits, int nbits, const int *to_bits, uint64_t konst, void *out_device, uint64_t needed,
+                    uint32_t skip_blocks, void **packed_at, int *fused);
 /* Lends the state a second device buffer of 2^n amplitudes for out-of-place tile passes (QSIM_OPT_PINGPONG) — e.g. the
  * exchange scratch of a sharded run, idle between exchanges.  The caller keeps ownership; between qsim_flush / qsim_sync
  * and the next gate the buffer is the caller's to use (its contents are garbage).  NULL takes it back. */
@@ -247,7 +279,12 @@ int qsim_cluster_norm2(qsim_cluster *c, double *out);
  * logical 2^12-amplitude blocks it holds a part of on its own device (qsim_block_prob_masked); the host adds the P
  * partial sums per block in shard order and fetches only the blocks the draws land in (qsim_gather_masked). */
 int qsim_cluster_sample(qsim_cluster *c, const double *randoms, long shots, uint64_t *out_indices);
-int qsim_cluster_exchange_stats(const qsim_cluster *c, uint64_t *exchanges, double *bytes_per_shard);
+int qsim_cluster_exchange_stats(const qsim_cluster *c, uint64_t *exchanges, double *bytes_per_shard); /* bytes: if every block travelled */
+/* What all shards together really sent: blocks of shards that hold nothing yet, and blocks for shards that will hold nothing
+ * afterwards, stay home (a run starts from |0...0>; qsim_shard_plan_step_support). */
+int qsim_cluster_exchange_bytes_moved(const qsim_cluster *c, double *bytes_all_shards);
+/* Re-layouts so far, per shard and exchange: done by the last tile pass in front of the exchange / by the pack kernel. */
+int qsim_cluster_pack_counts(const qsim_cluster *c, uint64_t *fused, uint64_t *separate);
 /* How this cluster moves blocks: "rccl" (every shard on its own device: one ncclGroup of ncclSend/ncclRecv per exchange,
  * stream-ordered), "direct" (all shards on one device: the pack kernel writes into the members' buffers, which then
  * change roles), "copies" (mixed placements: pack + device-to-device copies) or "none" (one shard). */
@@ -265,6 +302,20 @@ void qsim_shard_plan_free(qsim_shard_plan *p);
 int qsim_shard_plan_num_steps(const qsim_shard_plan *p);
 int qsim_shard_plan_step(const qsim_shard_plan *p, int step, int *kind, int *k, int *shard_bits, int *local_bits);
 int qsim_shard_plan_final_pos(const qsim_shard_plan *p, int *pos /* num_q entries: logical -> physical */);
+/* For an exchange step: where the register can be non-zero just before it, as sets of local positions / shard-id bits (a qubit
+ * stays |0> until a non-diagonal gate, or a CX whose control may be 1, acts on it).  The same on every rank. */
+int qsim_shard_plan_step_support(const qsim_shard_plan *p, int step, uint64_t *mixed_local, uint64_t *mixed_rank);
+/* What that means for one shard in the exchange of `step` (host only; what qsim_cluster / qsim_rank_comm act on).  The shard is
+ * member `mine` of its group; block b of its packed layout goes to member b and block b of its new contents comes from member b.
+ * send / recv: bit b set = that block really travels (never bit `mine`); keep_own: block `mine` stays and holds data; unread:
+ * blocks of the packed layout nobody looks at; empty_before / empty_after: the shard holds nothing (all zero) before / after;
+ * new_support: local index bits that may be 1 in its new contents (qsim_set_support). */
+typedef struct {
+    int mine, empty_before, empty_after, keep_own;
+    uint32_t send, recv, unread;
+    uint64_t new_support;
+} qsim_exchange_roles;
+int qsim_shard_plan_exchange_roles(const qsim_shard_plan *p, int step, int shard, qsim_exchange_roles *out);
 int qsim_shard_plan_local_ops(const qsim_shard_plan *p, int step, int shard, qsim_local_op_cb cb, void *user);
 int qsim_shard_plan_apply_local(const qsim_shard_plan *p, int step, int shard, qsim_state *s);
 /* Cost model of the plan's exchanges on one fully connected xGMI node: bytes each rank sends, and seconds =
@@ -288,7 +339,12 @@ int qsim_rccl_unique_id(void *id_bytes);
 int qsim_rank_comm_create(qsim_rank_comm **out, qsim_state *shard, int device, int world, int rank, const void *id_bytes, void *scratch_device);
 void qsim_rank_comm_destroy(qsim_rank_comm *c);
 int qsim_rank_comm_exchange(qsim_rank_comm *c, const int *shard_bits, const int *local_bits, int k);
+/* The exchange of step `step` of a plan, using what the plan knows about the state there (qsim_shard_plan_step_support): ranks
+ * that hold nothing do not pack or send, blocks that are zero throughout are not received, and the shard's engine is told
+ * where its new contents can be non-zero (qsim_set_support) or that it holds nothing (qsim_reset_shard). */
+int qsim_rank_comm_exchange_step(qsim_rank_comm *c, const qsim_shard_plan *p, int step);
 int qsim_rank_comm_stats(qsim_rank_comm *c, uint64_t *exchanges, double *bytes_sent, double *seconds, int reset);
+int qsim_rank_comm_pack_counts(const qsim_rank_comm *c, uint64_t *fused, uint64_t *separate); /* as qsim_cluster_pack_counts */
 /* Diagnostic: `count` doubles of the shard through ncclSend -> ncclRecv to this same rank, compared on the host (drives
  * the RCCL call path where only one GPU is present). */
 int qsim_rank_comm_loopback(qsim_rank_comm *c, uint64_t count);
@@ -303,6 +359,9 @@ long qsim_launch_log(qsim_state *s, long index, int *kernel_class, int *n_ops, u
  * the first three are walked by the lanes of a wave, the next by its waves, the last by a lane's registers); count = 0
  * for other kernels.  order needs room for 10 entries. */
 int qsim_launch_log_order(qsim_state *s, long index, int *order, int *count);
+/* ... and the fraction of the register's tiles it worked on (1 for a full sweep and for other kernels; less while the state's
+ * support is partial, QSIM_OPT_SPARSE_START / qsim_set_support). */
+int qsim_launch_log_visited(qsim_state *s, long index, double *visited);
 
 /* ---- circuits: the tokenizer of compute_state_vector (quantum_simulator.c:115-254) ---------------- */
 /* Parses the OPENQASM-3 subset of quantum_simulator.c (two header statements, `qubit[n] q;` or

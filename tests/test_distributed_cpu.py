@@ -196,3 +196,98 @@ def test_bench_plain_command_with_more_gpus_than_present_fails_cleanly():
     assert p.returncode != 0
     assert "2 GPUs requested" in p.stderr and "present" in p.stderr
     assert '{"metric"' not in p.stdout
+
+
+def _pack_np(state, m, Lsel):
+    """numpy restatement of k_pack: block index = the Lsel bits, rest = the other bits in order."""
+    k = len(Lsel)
+    d = np.arange(1 << m, dtype=np.int64)
+    rest, blk = d & ((1 << (m - k)) - 1), d >> (m - k)
+    keep = [b for b in range(m) if b not in Lsel]
+    src = np.zeros_like(d)
+    for i, b in enumerate(keep):
+        src |= ((rest >> i) & 1) << b
+    for i, b in enumerate(Lsel):
+        src |= ((blk >> i) & 1) << b
+    return state[src]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("n,depth,seed,vocab", [(7, 120, 21, "all"), (10, 400, 22, "all"), (12, 500, 23, "clifford_t"), (11, 60, 24, "all")])
+def test_sparse_exchange_protocol_on_poisoned_memory(oracle, tmp_path, world, n, depth, seed, vocab):
+    """What an exchange may leave out (csrc/dist.cpp roles_of; qsim_shard_plan_exchange_roles): shards that hold nothing
+    neither pack nor send, blocks that are zero throughout are not received, and a receiver only ever looks inside its
+    new support.  Modelled here with numpy shards whose memory is NaN wherever the protocol did not write: if a block that
+    matters stayed home, or a support were too small, the NaNs (or wrong amplitudes) reach the gathered state."""
+    gates = circuits.random_gates(n, depth, seed, vocab)
+    want = _oracle_state(oracle, tmp_path, n, gates)
+    p = world.bit_length() - 1
+    m = n - p
+    norm = normalize_gates(gates, gate_matrix)
+    plans = [ShardPlan(n, p, norm, r) for r in range(world)]
+    h = plans[0].handle
+    idx = np.arange(1 << m, dtype=np.int64)
+    full = (1 << m) - 1
+    mem = [np.full(1 << m, np.nan + 0j) for _ in range(world)]
+    support = [full] * world
+    empty = [r != 0 for r in range(world)]
+    mem[0][:] = 0
+    mem[0][0] = 1.0
+    saved_blocks = 0
+    for i, st in enumerate(plans[0].steps):
+        if st[0] == "local":
+            for r in range(world):
+                if empty[r]:
+                    continue  # every gate maps the zero vector to itself: the engine drops the queue
+                s = np.where((idx & ~support[r]) == 0, mem[r], 0)  # outside the support: zero by definition, whatever memory holds
+                assert not np.isnan(s).any(), "the support covers memory the exchange never wrote"
+                for op in plans[r].steps[i][1]:
+                    if op[0] == "cx":
+                        oracle.apply_cx(s, m, op[1], op[2])
+                    elif op[0] == "u1":
+                        oracle.apply_1q(s, m, np.asarray(op[2]).T, op[1])
+                    else:
+                        s *= op[1]
+                mem[r], support[r] = s, full
+            continue
+        _, J, Lsel = st
+        k = len(J)
+        blk = 1 << (m - k)
+        roles = [h.exchange_roles(i, r) for r in range(world)]
+        mixed_local, mixed_rank = h.step_support(i)
+        packed = []
+        for r in range(world):
+            ro = roles[r]
+            assert bool(ro["empty_before"]) == empty[r]  # a shard-id bit cannot be mixed while it is one: empty stays empty between exchanges
+            if ro["empty_before"]:
+                packed.append(None)
+                continue
+            pk = _pack_np(mem[r], m, list(Lsel)).copy()
+            for b in range(1 << k):
+                if ro["unread"] >> b & 1:
+                    pk[b * blk:(b + 1) * blk] = np.nan  # never written
+            packed.append(pk)
+        new_mem = [np.full(1 << m, np.nan + 0j) for _ in range(world)]
+        for r in range(world):
+            ro = roles[r]
+            mine, members = peers_of(r, J)
+            assert mine == ro["mine"]
+            for b in range(1 << k):
+                if ro["recv"] >> b & 1:
+                    assert roles[members[b]]["send"] >> mine & 1, "a receive without the matching send would hang RCCL"
+                    new_mem[r][b * blk:(b + 1) * blk] = packed[members[b]][mine * blk:(mine + 1) * blk]
+                elif b != mine:
+                    saved_blocks += 1
+                if ro["send"] >> b & 1:
+                    assert roles[members[b]]["recv"] >> mine & 1, "a send without the matching receive would hang RCCL"
+            if ro["keep_own"]:
+                new_mem[r][mine * blk:(mine + 1) * blk] = packed[r][mine * blk:(mine + 1) * blk]
+            empty[r] = bool(ro["empty_after"])
+            support[r] = ro["new_support"]
+        mem = new_mem
+    phys = np.concatenate([np.zeros(1 << m, dtype=np.complex128) if empty[r] else np.where((idx & ~support[r]) == 0, mem[r], 0) for r in range(world)])
+    assert not np.isnan(phys).any()
+    got = logical_from_physical(phys, plans[0].final_pos)
+    assert np.max(np.abs(got - want)) < TOL
+    if plans[0].exchanges:
+        assert saved_blocks > 0  # the first exchange of a run always has empty shards (the initial global qubits are still |0>)

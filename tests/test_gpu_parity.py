@@ -1087,3 +1087,218 @@ def test_planning_keeps_the_cheaper_of_the_two_schedules(oracle, tmp_path):
             assert moved <= costs[best] * (1 + 2e-3), (seed, costs, moved)
     lib.qsim_tune_table_clear()
     assert seen == {0, 1}  # both outcomes were exercised
+
+
+def test_plan_cache_does_not_trust_its_key(oracle, tmp_path):
+    """the plan cache found plans by a 64-bit FNV-1a key alone.  With QSIM_OPT_DEBUG_PLAN_KEY every queue gets
+    the SAME key; two different circuits of the same length must still each get their own, correct schedule — a cached
+    plan is only replayed after its gate list, options, support and scheduler overrides have been compared."""
+    n, depth = 16, 300
+    wants, circs = [], []
+    for seed in (71, 72, 73):
+        gates = circuits.random_gates(n, depth, seed, "all")
+        path = circuits.write_qasm(str(tmp_path / f"k{seed}.qasm"), n, gates)
+        wants.append(oracle.run_qasm(path)[1])
+        circs.append(Circuit.from_file(path))
+    with Simulator(n, fuse=3, debug_plan_key=12345) as sim:
+        for rep in range(3):
+            for c, want in zip(circs, wants):
+                sim.reset(); sim.run(c)
+                assert np.max(np.abs(sim.read() - want)) < TOL, rep
+        st = sim.plan_cache_stats()
+        assert st["plans"] == 3 and st["replays"] == 6     # every circuit planned once, replayed twice
+        assert st["key_collisions"] >= 6                    # ... and each replay had to walk past the others' plans
+        os.environ["QSIM_SCHED_NOCOMMUTE"] = "1"            # a scheduler override is part of a plan's identity too
+        try:
+            sim.reset(); sim.run(circs[0])
+            assert np.max(np.abs(sim.read() - wants[0])) < TOL
+            assert sim.plan_cache_stats()["replays"] == 6
+        finally:
+            os.environ.pop("QSIM_SCHED_NOCOMMUTE", None)
+
+
+def test_support_api_and_zero_shard_semantics(oracle, tmp_path):
+    """qsim_set_support / qsim_get_support / the all-zero vector: what the receiving side of a sparse exchange relies on.
+    A state declared zero outside a support, with NaNs in that memory, behaves exactly like the zero-padded state; gates on
+    a shard that holds nothing are dropped and it reads back as zeros."""
+    import torch
+    n = 15
+    gates = circuits.random_gates(n, 300, 91, "all")
+    path = circuits.write_qasm(str(tmp_path / "s.qasm"), n, gates)
+    c = Circuit.from_file(path)
+    rng = np.random.default_rng(5)
+    support = sum(1 << b for b in (0, 1, 2, 3, 5, 6, 9, 10, 12))
+    idx = np.arange(1 << n)
+    inside = (idx & ~support) == 0
+    init = np.where(inside, rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n), 0)
+    init /= np.linalg.norm(init)
+    want = init.copy()
+    for g in gates:
+        if g[0] == "cx":
+            oracle.apply_cx(want, n, g[1], g[2])
+        else:
+            tok = f"rz({g[1]!r})" if g[0] == "rz" else g[0]
+            oracle.apply_1q(want, n, np.ascontiguousarray(gate_matrix(tok).T), g[-1])
+    for pingpong in (0, 2):
+        with Simulator(n, fuse=3, pingpong=pingpong) as sim:
+            poisoned = np.where(inside, init, np.nan + 1j * np.nan)
+            sim.write(poisoned)
+            sim.set_support(support)
+            assert sim.get_support() == (support, False, 0.0)
+            sim.run(c)
+            got = sim.read()
+            assert not np.isnan(got).any()
+            assert np.max(np.abs(got - want)) < TOL
+            assert sim.get_support()[0] == (1 << n) - 1
+            # a shard that holds nothing: gates are dropped, reads give zeros, the norm is 0
+            sim.reset(holds_index0=False)
+            sim.run(c)
+            sim.flush()
+            assert sim.get_support() == (0, True, 0.0)
+            assert sim.norm2() == 0.0 and not sim.read().any()
+
+
+@pytest.mark.parametrize("shards", [2, 4, 8])
+def test_cluster_exchanges_leave_out_what_is_zero(oracle, tmp_path, shards):
+    """Support carried through exchanges (csrc/dist.cpp roles_of): the first exchanges of a run move only the blocks that can
+    be non-zero, shards that hold nothing do no work, and the shards keep visiting only their support afterwards — with
+    stale amplitudes of an earlier, unrelated run in every buffer (state and exchange scratch).  Same amplitudes as the oracle."""
+    from gpu_quantum_simulator_amd import Cluster
+    n = 18
+    stale = Circuit.from_file(circuits.random_circuit_file(str(tmp_path / "stale.qasm"), n, 500, 7, "all"))
+    for seed, depth in ((301, 700), (302, 80)):
+        path = circuits.random_circuit_file(str(tmp_path / f"c{seed}.qasm"), n, depth, seed + shards, "all")
+        _, want, _, _ = oracle.run_qasm(path)
+        c = Circuit.from_file(path)
+        with Cluster(n, shards, devices=[0] * shards) as cl:
+            cl.run(stale)  # leaves dense garbage in the state and scratch buffers of every shard
+            cl.run(stale)
+            moved0, (ex0, dense0) = cl.exchange_bytes_moved(), cl.exchange_stats()
+            cl.run(c)
+            got = cl.read()
+            assert np.max(np.abs(got - want)) < TOL
+            assert abs(cl.norm2() - 1.0) < 1e-10
+            ex, dense_per_shard = cl.exchange_stats()
+            ex, dense_per_shard = ex - ex0, dense_per_shard - dense0
+            if depth == 700:
+                assert ex >= 2
+            moved = cl.exchange_bytes_moved() - moved0
+            assert (moved > 0) == (ex > 0)
+            assert ex == 0 or moved < dense_per_shard * shards  # something stayed home: the first exchange has shards that hold nothing
+            fused, separate = cl.pack_counts()
+            assert fused + separate > 0 and (depth != 700 or fused > 0)  # most re-layouts ride on the last tile pass before the exchange
+
+
+def _pack_src_index(n, bits):
+    k = len(bits)
+    d = np.arange(1 << n, dtype=np.int64)
+    rest, blk = d & ((1 << (n - k)) - 1), d >> (n - k)
+    keep = [b for b in range(n) if b not in bits]
+    src = np.zeros_like(d)
+    for i, b in enumerate(keep):
+        src |= ((rest >> i) & 1) << b
+    for i, b in enumerate(bits):
+        src |= ((blk >> i) & 1) << b
+    return src
+
+
+@pytest.mark.parametrize("bits", [(5,), (3, 11), (0, 9), (4, 12, 13), (1, 2, 6), (12, 13, 14)])
+@pytest.mark.parametrize("pingpong", [0, 2])
+def test_flush_pack_last_pass_does_the_relayout(oracle, tmp_path, bits, pingpong):
+    """qsim_flush_pack: the last tile pass of the queue writes the state straight into the packed layout of an exchange
+    (k_tile PACK, a permutation of index bits applied to every store address).  Same amplitudes in the same places as
+    qsim_flush followed by qsim_pack_bits — on a dense state, with out-of-place passes in front, and into a larger buffer
+    with the blocks steered by to_bits / konst (the form a cluster with one allocation for all shards uses)."""
+    import torch
+    n = 15
+    gates = circuits.random_gates(n, 400, 77, "all")
+    path = circuits.write_qasm(str(tmp_path / "fp.qasm"), n, gates)
+    _, want, _, _ = oracle.run_qasm(path)
+    c = Circuit.from_file(path)
+    src = _pack_src_index(n, bits)
+    k = len(bits)
+    with Simulator(n, fuse=3, pingpong=pingpong) as sim:
+        out = torch.full((1 << n, 2), float("nan"), dtype=torch.float64, device="cuda")
+        big = torch.full((4 << n, 2), float("nan"), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        for rep in range(2):  # second time: the cached plan is replayed
+            sim.reset()
+            sim.run(c)
+            at, fused = sim.flush_pack(bits, out.data_ptr())
+            sim.sync()
+            assert fused and at == out.data_ptr()
+            got = out.cpu().numpy().reshape(-1).view(np.complex128)
+            assert np.max(np.abs(got - want[src])) < TOL, rep
+        # blocks steered into a buffer four times the size: block b -> index bits to_bits, plus a constant offset
+        to_bits = [n + 1 - j for j in range(k)] if k <= 2 else [n - k + j for j in range(k)]
+        konst = (1 << (n + 1)) if k == 1 else 0
+        sim.reset()
+        sim.run(c)
+        at, fused = sim.flush_pack(bits, big.data_ptr(), to_bits=to_bits, konst=konst)
+        sim.sync()
+        assert fused
+        gotb = big.cpu().numpy().reshape(-1).view(np.complex128)
+        blk = 1 << (n - k)
+        for b in range(1 << k):
+            start = konst | sum(((b >> j) & 1) << to_bits[j] for j in range(k))
+            assert np.max(np.abs(gotb[start:start + blk] - want[src][b * blk:(b + 1) * blk])) < TOL, b
+        assert np.isnan(gotb).sum() == (3 << n)  # nothing else was written
+
+
+def test_flush_pack_on_partial_states_and_fallbacks(oracle, tmp_path):
+    """The fused re-layout only writes what its pass visits: with a partially written state it is used when that covers what
+    the receivers need and replaced by the pack kernel (which writes the zeros) when it does not; queues that do not end in
+    a tile pass, empty queues and tiny registers take the pack kernel too.  Always the same packed amplitudes."""
+    import torch
+    n = 16
+    bits = (3, 14)
+    src = _pack_src_index(n, bits)
+    # gates on the low 11 qubits only: the state stays partial (support = bits 0..10 + padding of one tile)
+    gates = [g for g in circuits.random_gates(11, 200, 5, "all")]
+    path = circuits.write_qasm(str(tmp_path / "p.qasm"), n, gates)
+    _, want, _, _ = oracle.run_qasm(path)
+    c = Circuit.from_file(path)
+    low = (1 << 11) - 1
+    with Simulator(n, fuse=3) as sim:
+        out = torch.full((1 << n, 2), float("nan"), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        sim.run(c)
+        sup_needed = low
+        at, fused = sim.flush_pack(bits, out.data_ptr(), needed=sup_needed)
+        sim.sync()
+        assert fused
+        got = out.cpu().numpy().reshape(-1).view(np.complex128)
+        inside = (src & ~low) == 0
+        assert np.max(np.abs(got[inside] - want[src][inside])) < TOL  # where the receivers look
+        # needed = everything: the pass would leave most of the buffer unwritten -> pack kernel, zeros included
+        out.fill_(float("nan")); torch.cuda.synchronize()
+        sim.reset(); sim.run(c)
+        at, fused = sim.flush_pack(bits, out.data_ptr())
+        sim.sync()
+        assert not fused
+        got = out.cpu().numpy().reshape(-1).view(np.complex128)
+        assert np.max(np.abs(got - want[src])) < TOL
+        # a queue that ends in a single-gate kernel (fuse 0), and an empty queue on a dense state
+        sim.set_option(_lib.OPT_FUSE, 0)
+        sim.reset(); sim.run(c)
+        at, fused = sim.flush_pack(bits, out.data_ptr())
+        sim.sync()
+        assert not fused
+        assert np.max(np.abs(out.cpu().numpy().reshape(-1).view(np.complex128) - want[src])) < TOL
+        at, fused = sim.flush_pack(bits, out.data_ptr())
+        sim.sync()
+        assert not fused
+        assert np.max(np.abs(out.cpu().numpy().reshape(-1).view(np.complex128) - want[src])) < TOL
+    # tiles smaller than the production shape: no fused variant, same result
+    n2 = 10
+    g2 = circuits.random_gates(n2, 150, 9, "all")
+    p2 = circuits.write_qasm(str(tmp_path / "s.qasm"), n2, g2)
+    _, w2, _, _ = oracle.run_qasm(p2)
+    with Simulator(n2, fuse=3) as sim:
+        out = torch.zeros((1 << n2, 2), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        sim.run(Circuit.from_file(p2))
+        at, fused = sim.flush_pack((2, 7), out.data_ptr())
+        sim.sync()
+        assert not fused
+        assert np.max(np.abs(out.cpu().numpy().reshape(-1).view(np.complex128) - w2[_pack_src_index(n2, (2, 7))])) < TOL

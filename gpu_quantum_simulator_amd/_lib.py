@@ -141,6 +141,9 @@ SIGNATURES = {
     "qsim_tune_circuit": (c_int, [c_void_p, c_void_p, c_int, c_double, POINTER(QsimTuneReport)]),
     "qsim_choose_schedule": (c_int, [c_void_p, c_void_p]),
     "qsim_tune_circuit_from": (c_int, [c_void_p, c_void_p, c_int, c_double, POINTER(QsimTuneReport), c_int]),
+    "qsim_choose_schedule_for": (c_int, [c_void_p, c_void_p, c_uint64]),
+    "qsim_tune_circuit_support": (c_int, [c_void_p, c_void_p, c_int, c_double, POINTER(QsimTuneReport), c_uint64]),
+    "qsim_cluster_plan": (c_int, [c_void_p, c_void_p, c_int, c_double]),
     "qsim_tune_table_size": (c_long, []),
     "qsim_tune_table_clear": (None, []),
     "qsim_tune_table_save": (c_int, [c_char_p]),
@@ -159,6 +162,7 @@ SIGNATURES = {
     "qsim_run_circuit": (c_int, [c_void_p, c_void_p, c_long, c_long]),
     "qsim_gate_matrix": (c_int, [c_char_p, _DP]),
     "qsim_plan_circuit": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(QsimStats)]),
+    "qsim_plan_circuit_from": (c_int, [c_void_p, c_int, c_int, c_int, c_uint64, POINTER(QsimStats)]),
     "qsim_schedule_circuit": (c_int, [c_void_p, c_int, c_int, c_int, c_int, SCHED_CB, c_void_p]),
 }
 # include/qsim_legacy.h

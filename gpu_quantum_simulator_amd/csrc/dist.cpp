@@ -17,6 +17,7 @@
 #include <complex>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,6 +26,7 @@
 
 #include "circuit.h"
 #include "qsim_internal.h"
+#include "scheduler.h"
 
 using cd = std::complex<double>;
 
@@ -60,6 +62,7 @@ struct Plan {
     std::vector<Step> steps;
     std::vector<int> final_pos;
     int exchanges = 0;
+    int tail_gates = 0; // gate statements handed on across an exchange (small_tail)
 };
 
 constexpr long kInf = 1L << 60;
@@ -99,138 +102,6 @@ std::vector<int> choose_globals(const std::vector<LGate> &gates, const std::vect
     });
     order.resize(p);
     return order;
-}
-
-bool build_plan_policy(int n, int p, const std::vector<LGate> &gates, Plan &plan, bool full_swap) {
-    const int P = 1 << p, m = n - p;
-    plan.n = n; plan.p = p; plan.m = m;
-    std::vector<int> pos(n);
-    for (int q = 0; q < n; q++) pos[q] = q;
-    std::vector<LGate> remaining(gates);
-    bool first = true;
-    uint64_t mixed = 0; // logical qubits that may be 1 somewhere in the state (Step::mixed_local / mixed_rank)
-    while (!remaining.empty()) {
-        if (p && first) { // free initial placement
-            std::vector<int> ng = choose_globals(remaining, pos, n, p, m);
-            std::vector<int> outgoing, incoming;
-            for (int q : ng) if (pos[q] < m) outgoing.push_back(q);
-            for (int q = 0; q < n; q++)
-                if (pos[q] >= m && std::find(ng.begin(), ng.end(), q) == ng.end()) incoming.push_back(q);
-            for (size_t i = 0; i < outgoing.size() && i < incoming.size(); i++) std::swap(pos[outgoing[i]], pos[incoming[i]]);
-        }
-        first = false;
-        // split into runnable / deferred
-        std::vector<LGate> run, deferred;
-        uint64_t blocked = 0;
-        for (const LGate &g : remaining) {
-            uint64_t qs = 1ULL << g.q0;
-            if (g.kind == QSIM_GATE_CX) qs |= 1ULL << g.q1;
-            if (qs & blocked) { blocked |= qs; deferred.push_back(g); continue; }
-            int q[2], c;
-            needs_local(g, q, c);
-            bool ok = true;
-            for (int k = 0; k < c; k++) ok = ok && pos[q[k]] < m;
-            if (ok) run.push_back(g);
-            else { blocked |= qs; deferred.push_back(g); }
-        }
-        for (const LGate &g : run) { // in program order
-            if (g.kind == QSIM_GATE_CX) { if (g.q0 != g.q1 && (mixed >> g.q0 & 1ULL)) mixed |= 1ULL << g.q1; }
-            else if (!g.diag()) mixed |= 1ULL << g.q0;
-        }
-        if (!run.empty()) {
-            Step st;
-            st.per_shard.resize(P);
-            for (int r = 0; r < P; r++) {
-                std::vector<LocalOp> &ops = st.per_shard[r];
-                for (const LGate &g : run) {
-                    LocalOp o{};
-                    if (g.kind == QSIM_GATE_CX) {
-                        if (g.q0 == g.q1) continue;
-                        if (pos[g.q0] < m) { o.kind = 2; o.a = pos[g.q0]; o.b = pos[g.q1]; ops.push_back(o); }
-                        else if ((r >> (pos[g.q0] - m)) & 1) {
-                            o.kind = 1; o.a = pos[g.q1];
-                            o.m[0] = 0; o.m[1] = 1; o.m[2] = 1; o.m[3] = 0;
-                            ops.push_back(o);
-                        }
-                    } else if (pos[g.q0] < m) {
-                        o.kind = 1; o.a = pos[g.q0];
-                        std::copy(g.m, g.m + 4, o.m);
-                        ops.push_back(o);
-                    } else {
-                        const int b = (r >> (pos[g.q0] - m)) & 1;
-                        const cd z = g.m[b ? 3 : 0];
-                        if (z != cd(1, 0)) { o.kind = 3; o.m[0] = z; ops.push_back(o); }
-                    }
-                }
-            }
-            plan.steps.push_back(std::move(st));
-        }
-        if (!deferred.empty()) {
-            std::vector<int> ng = choose_globals(deferred, pos, n, p, m, full_swap);
-            std::vector<int> outgoing, incoming;
-            for (int q : ng) if (pos[q] < m) outgoing.push_back(q);
-            for (int q = 0; q < n; q++)
-                if (pos[q] >= m && std::find(ng.begin(), ng.end(), q) == ng.end()) incoming.push_back(q);
-            std::sort(outgoing.begin(), outgoing.end(), [&](int a, int b) { return pos[a] < pos[b]; });
-            std::sort(incoming.begin(), incoming.end(), [&](int a, int b) { return pos[a] < pos[b]; });
-            const int k = (int)outgoing.size();
-            if (k == 0 || k != (int)incoming.size()) return false; // no progress possible
-            Step st;
-            st.exchange = true;
-            for (int q : outgoing) st.Lsel.push_back(pos[q]);
-            for (int q : incoming) st.J.push_back(pos[q] - m);
-            for (int q = 0; q < n; q++)
-                if (mixed >> q & 1ULL) (pos[q] < m ? st.mixed_local : st.mixed_rank) |= 1ULL << (pos[q] < m ? pos[q] : pos[q] - m);
-            std::vector<int> np(pos);
-            for (int q = 0; q < n; q++)
-                if (pos[q] < m && std::find(st.Lsel.begin(), st.Lsel.end(), pos[q]) == st.Lsel.end()) {
-                    int below = 0;
-                    for (int s : st.Lsel) below += s < pos[q];
-                    np[q] = pos[q] - below;
-                }
-            for (int i = 0; i < k; i++) np[incoming[i]] = m - k + i;
-            for (int i = 0; i < k; i++) np[outgoing[i]] = m + st.J[i];
-            pos = np;
-            plan.steps.push_back(std::move(st));
-            plan.exchanges++;
-        }
-        remaining.swap(deferred);
-    }
-    plan.final_pos = pos;
-    return true;
-}
-
-// Exchange cost of a plan in integer units (so that the C++ planner and its Python twin decide identically): one
-// exchange of k qubits = a pack pass over the shard (2 S bytes of HBM traffic) + 2^-k of the shard over each of 2^k - 1
-// links in parallel.  With S / link = kLinkUnits and 2 S / HBM = kPackUnits (defaults: 50 GB/s per link direction, 5 TB/s
-// pack kernel, i.e. 200 : 1 per byte; qsim_shard_plan_predict takes the real figures) the cost is additive.
-constexpr long kLinkUnits = 25600, kPackUnits = 256;
-long plan_cost(const Plan &plan) {
-    long c = 0;
-    for (const Step &st : plan.steps)
-        if (st.exchange) c += kPackUnits + (kLinkUnits >> st.J.size());
-    return c;
-}
-
-// Two placement policies are planned in full and the cheaper plan (by plan_cost) is kept; ties keep the first.
-bool build_plan(int n, int p, const std::vector<LGate> &gates, Plan &plan) {
-    Plan keep, full;
-    if (!build_plan_policy(n, p, gates, keep, false)) return false;
-    if (p > 1 && build_plan_policy(n, p, gates, full, true) && plan_cost(full) < plan_cost(keep)) plan = std::move(full);
-    else plan = std::move(keep);
-    return true;
-}
-
-void gates_of(const qsim_circuit *c, std::vector<LGate> &out) {
-    out.reserve((size_t)c->count);
-    for (long i = 0; i < c->count; i++) {
-        const qsim_gate_rec &g = c->gates[i];
-        LGate lg{};
-        lg.kind = g.kind; lg.q0 = g.q0; lg.q1 = g.q1;
-        if (g.kind == QSIM_GATE_U1)
-            for (int k = 0; k < 4; k++) lg.m[k] = cd(c->mats2[8 * (long)g.mat + 2 * k], c->mats2[8 * (long)g.mat + 2 * k + 1]);
-        out.push_back(lg);
-    }
 }
 
 void peers_of(int rank, const std::vector<int> &J, int &mine, std::vector<int> &members) {
@@ -298,6 +169,238 @@ int settle(qsim_state *s, const Roles &r) {
     return r.empty_after ? qsim_reset_shard(s, 0) : qsim_set_support(s, r.new_support);
 }
 
+// The gates of `run` (indices) that the engine's scheduler would put into the LAST pass of the segment, when that pass is
+// a small one: the segment's gates are scheduled here exactly as a shard's engine will schedule them (same Scheduler, same
+// settings; the shard-dependent ops in their busiest form: a CX controlled by a shard-id bit as an X), with every pass
+// listing the gates it absorbed.  A segment ends where the next gate needs a qubit that is not local, not where a pass
+// is full, so its last pass often carries a handful of gates and still costs a whole sweep over the shard — on every
+// segment.  Those gates can just as well wait for the exchange: they come last in a valid order, and what they touch stays
+// local (the planner evicts by furthest next use, and theirs is now the nearest).
+std::vector<size_t> small_tail(const std::vector<LGate> &run, const std::vector<int> &pos, int m, bool from_reset, int max_gates) {
+    std::vector<size_t> out;
+    if (max_gates <= 0 || m < 12 || run.size() < 2) return out;
+    qsim::SchedConfig cfg = qsim::engine_sched_config(m, 3, 12, 3, 32, 10, false, from_reset ? 0 : ~0ULL);
+    cfg.track = 1;
+    qsim::Scheduler sched(cfg);
+    std::vector<size_t> which; // scheduler gate number -> index into run
+    static const cd X[4] = {cd(0, 0), cd(1, 0), cd(1, 0), cd(0, 0)};
+    for (size_t i = 0; i < run.size(); i++) {
+        const LGate &g = run[i];
+        if (g.kind == QSIM_GATE_CX) {
+            if (g.q0 == g.q1) continue;
+            if (pos[g.q0] < m) sched.add_cx(pos[g.q0], pos[g.q1]);
+            else sched.add_1q(X, pos[g.q1]);
+        } else if (pos[g.q0] < m) {
+            sched.add_1q(g.m, pos[g.q0]);
+        } else {
+            continue; // a factor per shard
+        }
+        which.push_back(i);
+    }
+    std::vector<qsim::Pass> passes;
+    sched.finish(passes);
+    if (passes.size() < 2 || passes.back().kclass != QSIM_K_TILE) return out;
+    const qsim::Pass &last = passes.back();
+    if ((int)last.src.size() > max_gates) return out;
+    for (uint32_t gi : last.src) out.push_back(which[gi]);
+    std::sort(out.begin(), out.end());
+    return out;
+}
+
+// Where a shard's state can be non-zero after a local step, as its engine will know it: the step's ops are scheduled exactly
+// as qsim_flush will schedule them, and whatever lies outside (support before | the tile qubits of the passes) has not been
+// touched since it was zero.  ANY valid schedule of the same ops gives a valid bound (the final state does not depend on the
+// schedule), so it does not matter whether the engine later takes this very schedule or another variant of it; what matters
+// is that every rank computes the same mask, which it does: same plan, same code.  Tighter than counting the qubits some
+// non-diagonal gate has touched (x q; cx q,t; x q leaves q where it was, and the fused cluster shows it).
+uint64_t scheduled_support(const std::vector<LocalOp> &ops, int m, uint64_t support) {
+    const uint64_t all = m >= 64 ? ~0ULL : ((1ULL << m) - 1ULL);
+    if ((support & all) == all || ops.empty()) return support & all;
+    qsim::Scheduler sched(qsim::engine_sched_config(m, 3, 12, 3, 32, 10, false, support & all));
+    for (const LocalOp &o : ops) {
+        if (o.kind == 2) sched.add_cx(o.a, o.b);
+        else if (o.kind == 1) sched.add_1q(o.m, o.a);
+        else { const cd d[4] = {o.m[0], cd(0, 0), cd(0, 0), o.m[0]}; sched.add_1q(d, 0); }
+    }
+    uint64_t sup = support & all;
+    sched.finish([&](qsim::Pass &&ps) {
+        if (ps.kclass != QSIM_K_TILE) { sup = all; return; } // a single-gate kernel: the engine writes the zeros out first
+        sup |= (1ULL << ps.geom.low_bits) - 1ULL;
+        for (int j = 0; j < ps.geom.n_high; j++) sup |= 1ULL << ps.geom.high[j];
+    });
+    return sup & all;
+}
+
+// QSIM_SHARD_TAIL: the largest last pass (in gate statements) that is handed on to the next segment; 0 = never (the plain
+// "run everything that can run" planner, which tests/py_shard_plan.py restates).  An experiment override like QSIM_SCHED_*.
+int tail_limit() {
+    if (const char *v = getenv("QSIM_SHARD_TAIL")) return atoi(v);
+    return 24;
+}
+
+bool build_plan_policy(int n, int p, const std::vector<LGate> &gates, Plan &plan, bool full_swap) {
+    const int P = 1 << p, m = n - p;
+    plan.n = n; plan.p = p; plan.m = m;
+    std::vector<int> pos(n);
+    for (int q = 0; q < n; q++) pos[q] = q;
+    std::vector<LGate> remaining(gates);
+    bool first = true;
+    uint64_t mixed = 0; // logical qubits some gate may have moved away from |0> (a first, gate-level bound for Step::mixed_local)
+    // ... and the bound the shards' engines will have themselves (scheduled_support), per shard; holds[r] = 0: shard r holds nothing
+    std::vector<uint64_t> sup((size_t)P, 0);
+    std::vector<char> holds((size_t)P, 0);
+    holds[0] = 1;
+    while (!remaining.empty()) {
+        if (p && first) { // free initial placement
+            std::vector<int> ng = choose_globals(remaining, pos, n, p, m);
+            std::vector<int> outgoing, incoming;
+            for (int q : ng) if (pos[q] < m) outgoing.push_back(q);
+            for (int q = 0; q < n; q++)
+                if (pos[q] >= m && std::find(ng.begin(), ng.end(), q) == ng.end()) incoming.push_back(q);
+            for (size_t i = 0; i < outgoing.size() && i < incoming.size(); i++) std::swap(pos[outgoing[i]], pos[incoming[i]]);
+        }
+        first = false;
+        // split into runnable / deferred
+        std::vector<LGate> run, deferred;
+        uint64_t blocked = 0;
+        for (const LGate &g : remaining) {
+            uint64_t qs = 1ULL << g.q0;
+            if (g.kind == QSIM_GATE_CX) qs |= 1ULL << g.q1;
+            if (qs & blocked) { blocked |= qs; deferred.push_back(g); continue; }
+            int q[2], c;
+            needs_local(g, q, c);
+            bool ok = true;
+            for (int k = 0; k < c; k++) ok = ok && pos[q[k]] < m;
+            if (ok) run.push_back(g);
+            else { blocked |= qs; deferred.push_back(g); }
+        }
+        if (p && !deferred.empty()) { // an exchange follows: a small last pass waits for it
+            const std::vector<size_t> tail = small_tail(run, pos, m, plan.steps.empty(), tail_limit());
+            if (!tail.empty()) {
+                std::vector<LGate> keep, moved;
+                size_t t = 0;
+                for (size_t i = 0; i < run.size(); i++) {
+                    if (t < tail.size() && tail[t] == i) { moved.push_back(run[i]); t++; }
+                    else keep.push_back(run[i]);
+                }
+                moved.insert(moved.end(), deferred.begin(), deferred.end()); // in front of what was deferred already: nothing there precedes them on a shared qubit
+                deferred.swap(moved);
+                run.swap(keep);
+                plan.tail_gates += (int)tail.size();
+            }
+        }
+        for (const LGate &g : run) { // in program order
+            if (g.kind == QSIM_GATE_CX) { if (g.q0 != g.q1 && (mixed >> g.q0 & 1ULL)) mixed |= 1ULL << g.q1; }
+            else if (!g.diag()) mixed |= 1ULL << g.q0;
+        }
+        if (!run.empty()) {
+            Step st;
+            st.per_shard.resize(P);
+            for (int r = 0; r < P; r++) {
+                std::vector<LocalOp> &ops = st.per_shard[r];
+                for (const LGate &g : run) {
+                    LocalOp o{};
+                    if (g.kind == QSIM_GATE_CX) {
+                        if (g.q0 == g.q1) continue;
+                        if (pos[g.q0] < m) { o.kind = 2; o.a = pos[g.q0]; o.b = pos[g.q1]; ops.push_back(o); }
+                        else if ((r >> (pos[g.q0] - m)) & 1) {
+                            o.kind = 1; o.a = pos[g.q1];
+                            o.m[0] = 0; o.m[1] = 1; o.m[2] = 1; o.m[3] = 0;
+                            ops.push_back(o);
+                        }
+                    } else if (pos[g.q0] < m) {
+                        o.kind = 1; o.a = pos[g.q0];
+                        std::copy(g.m, g.m + 4, o.m);
+                        ops.push_back(o);
+                    } else {
+                        const int b = (r >> (pos[g.q0] - m)) & 1;
+                        const cd z = g.m[b ? 3 : 0];
+                        if (z != cd(1, 0)) { o.kind = 3; o.m[0] = z; ops.push_back(o); }
+                    }
+                }
+            }
+            if (p)
+                for (int r = 0; r < P; r++)
+                    if (holds[(size_t)r]) sup[(size_t)r] = scheduled_support(st.per_shard[(size_t)r], m, sup[(size_t)r]);
+            plan.steps.push_back(std::move(st));
+        }
+        if (!deferred.empty()) {
+            std::vector<int> ng = choose_globals(deferred, pos, n, p, m, full_swap);
+            std::vector<int> outgoing, incoming;
+            for (int q : ng) if (pos[q] < m) outgoing.push_back(q);
+            for (int q = 0; q < n; q++)
+                if (pos[q] >= m && std::find(ng.begin(), ng.end(), q) == ng.end()) incoming.push_back(q);
+            std::sort(outgoing.begin(), outgoing.end(), [&](int a, int b) { return pos[a] < pos[b]; });
+            std::sort(incoming.begin(), incoming.end(), [&](int a, int b) { return pos[a] < pos[b]; });
+            const int k = (int)outgoing.size();
+            if (k == 0 || k != (int)incoming.size()) return false; // no progress possible
+            Step st;
+            st.exchange = true;
+            for (int q : outgoing) st.Lsel.push_back(pos[q]);
+            for (int q : incoming) st.J.push_back(pos[q] - m);
+            uint64_t gate_level = 0, engine_level = 0;
+            for (int q = 0; q < n; q++)
+                if ((mixed >> q & 1ULL) && pos[q] < m) gate_level |= 1ULL << pos[q];
+            for (int r = 0; r < P; r++)
+                if (holds[(size_t)r]) { engine_level |= sup[(size_t)r]; st.mixed_rank |= (uint64_t)r; }
+            st.mixed_local = gate_level & engine_level; // both are bounds on where the state can be non-zero
+            for (int r = 0; r < P; r++) { // what every shard holds afterwards
+                const Roles ro = roles_of(r, m, st);
+                holds[(size_t)r] = !ro.empty_after;
+                sup[(size_t)r] = ro.empty_after ? 0 : ro.new_support;
+            }
+            std::vector<int> np(pos);
+            for (int q = 0; q < n; q++)
+                if (pos[q] < m && std::find(st.Lsel.begin(), st.Lsel.end(), pos[q]) == st.Lsel.end()) {
+                    int below = 0;
+                    for (int s : st.Lsel) below += s < pos[q];
+                    np[q] = pos[q] - below;
+                }
+            for (int i = 0; i < k; i++) np[incoming[i]] = m - k + i;
+            for (int i = 0; i < k; i++) np[outgoing[i]] = m + st.J[i];
+            pos = np;
+            plan.steps.push_back(std::move(st));
+            plan.exchanges++;
+        }
+        remaining.swap(deferred);
+    }
+    plan.final_pos = pos;
+    return true;
+}
+
+// Exchange cost of a plan in integer units (so that the C++ planner and its Python twin decide identically): one
+// exchange of k qubits = a pack pass over the shard (2 S bytes of HBM traffic) + 2^-k of the shard over each of 2^k - 1
+// links in parallel.  With S / link = kLinkUnits and 2 S / HBM = kPackUnits (defaults: 50 GB/s per link direction, 5 TB/s
+// pack kernel, i.e. 200 : 1 per byte; qsim_shard_plan_predict takes the real figures) the cost is additive.
+constexpr long kLinkUnits = 25600, kPackUnits = 256;
+long plan_cost(const Plan &plan) {
+    long c = 0;
+    for (const Step &st : plan.steps)
+        if (st.exchange) c += kPackUnits + (kLinkUnits >> st.J.size());
+    return c;
+}
+
+// Two placement policies are planned in full and the cheaper plan (by plan_cost) is kept; ties keep the first.
+bool build_plan(int n, int p, const std::vector<LGate> &gates, Plan &plan) {
+    Plan keep, full;
+    if (!build_plan_policy(n, p, gates, keep, false)) return false;
+    if (p > 1 && build_plan_policy(n, p, gates, full, true) && plan_cost(full) < plan_cost(keep)) plan = std::move(full);
+    else plan = std::move(keep);
+    return true;
+}
+
+void gates_of(const qsim_circuit *c, std::vector<LGate> &out) {
+    out.reserve((size_t)c->count);
+    for (long i = 0; i < c->count; i++) {
+        const qsim_gate_rec &g = c->gates[i];
+        LGate lg{};
+        lg.kind = g.kind; lg.q0 = g.q0; lg.q1 = g.q1;
+        if (g.kind == QSIM_GATE_U1)
+            for (int k = 0; k < 4; k++) lg.m[k] = cd(c->mats2[8 * (long)g.mat + 2 * k], c->mats2[8 * (long)g.mat + 2 * k + 1]);
+        out.push_back(lg);
+    }
+}
+
 } // namespace
 
 struct qsim_cluster {
@@ -319,6 +422,10 @@ struct qsim_cluster {
     // of index bits across the whole pool (qsim_flush_pack) — the last tile pass before an exchange writes straight there.
     char *pool[2] = {nullptr, nullptr};
     int state_pool = 0; // which pool the states are in (exchanges flip it)
+    // the plan of the last circuit: a loop that runs one circuit again and again plans it once (compared gate by gate, not hashed)
+    std::vector<LGate> planned_gates;
+    Plan planned;
+    int planned_tail = -1;
     uint64_t fused_packs = 0, separate_packs = 0;
     std::vector<hipEvent_t> packed; // per shard: its pack of the current exchange has finished
 };
@@ -632,17 +739,19 @@ extern "C" const char *qsim_cluster_exchange_mode(const qsim_cluster *c) {
 
 // Plans and runs the circuit from the CURRENT state with the map reset to what the planner assumes, i.e. call
 // qsim_cluster_reset first (compute_state_vector semantics: one circuit per state).
+static int cluster_plan_for(qsim_cluster *c, const qsim_circuit *circ);
+static int plan_shard_steps(const Plan &plan, int shard, qsim_state *s, int max_candidates, double budget_ms, qsim_tune_report *total);
+
 extern "C" int qsim_cluster_run_circuit(qsim_cluster *c, const qsim_circuit *circ) {
     if (!c || !circ) return cfail(QSIM_ERR_ARG, "NULL argument");
     if (circ->num_q != c->n) return cfail(QSIM_ERR_ARG, "circuit has %d qubits, cluster has %d", circ->num_q, c->n);
     for (int q = 0; q < c->n; q++)
         if (c->pos[q] != q) return cfail(QSIM_ERR_ARG, "cluster already holds a permuted state: reset it first");
-    for (long i = 0; i < circ->count; i++)
-        if (circ->gates[i].kind == QSIM_GATE_U2) return cfail(QSIM_ERR_ARG, "generic 2-qubit gates are not supported on clusters");
-    std::vector<LGate> gates;
-    gates_of(circ, gates);
-    Plan plan;
-    if (!build_plan(c->n, c->p, gates, plan)) return cfail(QSIM_ERR_ARG, "planner made no progress");
+    {
+        const int rc = cluster_plan_for(c, circ);
+        if (rc) return rc;
+    }
+    const Plan &plan = c->planned;
     for (size_t i = 0; i < plan.steps.size(); i++) {
         const Step &st = plan.steps[i];
         const bool before_exchange = i + 1 < plan.steps.size() && plan.steps[i + 1].exchange;
@@ -651,6 +760,94 @@ extern "C" int qsim_cluster_run_circuit(qsim_cluster *c, const qsim_circuit *cir
     }
     c->pos = plan.final_pos;
     return QSIM_OK;
+}
+
+// One shard's ops of a local step as a circuit on its m local qubits (a per-shard factor as diag(z, z) on qubit 0: qsim_scale).
+static int step_circuit(const Step &st, int shard, int m, qsim_circuit **out) {
+    qsim_circuit *c = nullptr;
+    int rc = qsim_circuit_create(m, &c);
+    for (const LocalOp &o : st.per_shard[(size_t)shard]) {
+        if (rc) break;
+        if (o.kind == 2) rc = qsim_circuit_append_cx(c, o.a, o.b);
+        else {
+            const cd z = o.m[0];
+            const double U[8] = {o.m[0].real(), o.m[0].imag(), o.kind == 1 ? o.m[1].real() : 0.0, o.kind == 1 ? o.m[1].imag() : 0.0,
+                                 o.kind == 1 ? o.m[2].real() : 0.0, o.kind == 1 ? o.m[2].imag() : 0.0,
+                                 o.kind == 1 ? o.m[3].real() : z.real(), o.kind == 1 ? o.m[3].imag() : z.imag()};
+            rc = qsim_circuit_append_1q(c, U, o.kind == 1 ? o.a : 0);
+        }
+    }
+    if (rc) { qsim_circuit_free(c); return rc; }
+    *out = c;
+    return QSIM_OK;
+}
+
+// Planning of one shard's local steps: for each, the support the shard will have there (0 at the start on the shard that holds
+// index 0; after an exchange what roles_of says; a shard that holds nothing is skipped) and the schedule choice / geometry
+// tuning for exactly that situation.
+static int plan_shard_steps(const Plan &plan, int shard, qsim_state *s, int max_candidates, double budget_ms, qsim_tune_report *total) {
+    const uint64_t all = ~0ULL;
+    uint64_t support = 0;
+    bool empty = shard != 0;
+    int locals = 0;
+    for (const Step &st : plan.steps) locals += !st.exchange;
+    for (const Step &st : plan.steps) {
+        if (st.exchange) {
+            const Roles ro = roles_of(shard, plan.m, st);
+            empty = ro.empty_after;
+            support = ro.new_support;
+            continue;
+        }
+        if (empty) continue;
+        qsim_circuit *c = nullptr;
+        int rc = step_circuit(st, shard, plan.m, &c);
+        qsim_tune_report r{};
+        if (rc == QSIM_OK) {
+            if (max_candidates > 1) rc = qsim_tune_circuit_support(s, c, max_candidates, budget_ms > 0 ? budget_ms / locals : 0.0, &r, support);
+            else rc = qsim_choose_schedule_for(s, c, support);
+        }
+        qsim_circuit_free(c);
+        if (rc) return cfail(rc, "%s", qsim_last_error());
+        if (total) {
+            total->tile_passes += r.tile_passes; total->already_known += r.already_known; total->passes_tuned += r.passes_tuned;
+            total->passes_reordered += r.passes_reordered; total->candidates_timed += r.candidates_timed;
+            total->ms_ascending += r.ms_ascending; total->ms_best += r.ms_best; total->seconds += r.seconds;
+        }
+        support = all; // a local step leaves the shard dense (its passes cover every qubit, or nearly: the engine knows better, the key then simply misses)
+    }
+    return QSIM_OK;
+}
+
+static int cluster_plan_for(qsim_cluster *c, const qsim_circuit *circ) {
+    if (circ->num_q != c->n) return cfail(QSIM_ERR_ARG, "circuit has %d qubits, cluster has %d", circ->num_q, c->n);
+    for (long i = 0; i < circ->count; i++)
+        if (circ->gates[i].kind == QSIM_GATE_U2) return cfail(QSIM_ERR_ARG, "generic 2-qubit gates are not supported on clusters");
+    std::vector<LGate> gates;
+    gates_of(circ, gates);
+    bool same = c->planned_tail == tail_limit() && gates.size() == c->planned_gates.size();
+    for (size_t i = 0; same && i < gates.size(); i++) {
+        const LGate &a = gates[i], &b = c->planned_gates[i];
+        same = a.kind == b.kind && a.q0 == b.q0 && a.q1 == b.q1 && (a.kind != QSIM_GATE_U1 || memcmp(a.m, b.m, sizeof a.m) == 0);
+    }
+    if (!same) {
+        c->planned = Plan();
+        c->planned_tail = -1;
+        if (!build_plan(c->n, c->p, gates, c->planned)) return cfail(QSIM_ERR_ARG, "planner made no progress");
+        c->planned_gates.swap(gates);
+        c->planned_tail = tail_limit();
+    }
+    return QSIM_OK;
+}
+
+extern "C" int qsim_cluster_plan(qsim_cluster *c, const qsim_circuit *circ, int max_candidates, double budget_ms) {
+    if (!c || !circ) return cfail(QSIM_ERR_ARG, "NULL argument");
+    int rc = cluster_plan_for(c, circ);
+    if (rc) return rc;
+    for (int r = 0; r < c->P; r++) {
+        rc = plan_shard_steps(c->planned, r, c->shard[r], max_candidates, budget_ms > 0 ? budget_ms / c->P : 0.0, nullptr);
+        if (rc) return rc;
+    }
+    return qsim_cluster_reset(c);
 }
 
 extern "C" int qsim_cluster_sync(qsim_cluster *c) {
@@ -1129,32 +1326,8 @@ extern "C" int qsim_shard_plan_tune(const qsim_shard_plan *p, int shard, qsim_st
                                     qsim_tune_report *report) {
     if (!p || !s || shard < 0 || shard >= p->P) return cfail(QSIM_ERR_ARG, "bad argument");
     qsim_tune_report total{};
-    int locals = 0;
-    for (const Step &st : p->plan.steps) locals += !st.exchange;
-    bool exchanged = false; // local steps after the first exchange start from a dense shard, the first one from a reset
-    for (const Step &st : p->plan.steps) {
-        if (st.exchange) { exchanged = true; continue; }
-        qsim_circuit *c = nullptr;
-        int rc = qsim_circuit_create(p->plan.m, &c);
-        for (const LocalOp &o : st.per_shard[(size_t)shard]) {
-            if (rc) break;
-            if (o.kind == 2) rc = qsim_circuit_append_cx(c, o.a, o.b);
-            else {
-                const cd z = o.m[0];
-                const double U[8] = {o.m[0].real(), o.m[0].imag(), o.kind == 1 ? o.m[1].real() : 0.0, o.kind == 1 ? o.m[1].imag() : 0.0,
-                                     o.kind == 1 ? o.m[2].real() : 0.0, o.kind == 1 ? o.m[2].imag() : 0.0,
-                                     o.kind == 1 ? o.m[3].real() : z.real(), o.kind == 1 ? o.m[3].imag() : z.imag()};
-                rc = qsim_circuit_append_1q(c, U, o.kind == 1 ? o.a : 0); // kind 3: the scalar as diag(z, z) on local qubit 0 (qsim_scale)
-            }
-        }
-        qsim_tune_report r{};
-        if (rc == QSIM_OK) rc = qsim_tune_circuit_from(s, c, max_candidates, budget_ms > 0 ? budget_ms / locals : 0.0, &r, exchanged ? 1 : 0);
-        qsim_circuit_free(c);
-        if (rc) return cfail(rc, "%s", qsim_last_error());
-        total.tile_passes += r.tile_passes; total.already_known += r.already_known; total.passes_tuned += r.passes_tuned;
-        total.passes_reordered += r.passes_reordered; total.candidates_timed += r.candidates_timed;
-        total.ms_ascending += r.ms_ascending; total.ms_best += r.ms_best; total.seconds += r.seconds;
-    }
+    const int rc = plan_shard_steps(p->plan, shard, s, max_candidates < 2 ? 2 : max_candidates, budget_ms, &total);
+    if (rc) return rc;
     if (report) *report = total;
     return QSIM_OK;
 }

@@ -490,27 +490,7 @@ extern "C" int qsim_apply_2q(qsim_state *s, const double *U, int q_hi, int q_lo)
 // ---- scheduling + launch -------------------------------------------------------------------------------
 static SchedConfig sched_config(int n, int fuse, int tile_bits, int tile_low_bits, int tile_max_ops, int pad_from = 10, bool f32 = false,
                                 uint64_t initial_support = 0) {
-    SchedConfig c;
-    c.pad_from = pad_from;
-    c.initial_support = initial_support; // 0: the run starts from a reset (what the planning entry points assume)
-    c.n = n; c.fuse = fuse; c.tile_bits = tile_bits; c.tile_low_bits = tile_low_bits; c.tile_max_ops = tile_max_ops;
-    // The pass-set local search (SchedConfig::local_iters with one pass of lookahead) costs ~1.5 ms of host time per
-    // pass.  Passes are launched as they are produced, so the search is free once a pass runs longer than that on the
-    // GPU: from 4 GiB of state (n = 28 fp64: 1.9 ms per pass).  Since the row-class form of the sparse blocks (one LDS
-    // read per amplitude) most passes are bound by their memory time again, so one pass less is ~7 ms less at n = 30
-    // (round 1: the fuller passes were LDS-bound and the total did not move).  With the search on, a pass is capped at
-    // 24 clusters (5-6 merged blocks): ~1.6 + 0.8 ms per block then stays under the pass's ~6.8 ms of memory time.
-    // Twelve seeded 1000-gate circuits at n = 30: 204 passes without the search, 188 with it (191 / 193 with two /
-    // three passes of lookahead, which also cost more host time, so one it is).  n = 30 bench circuit: 16 passes /
-    // 119.7 ms without, 15 / 115.5 ms with; n = 28: 31.1 -> 29.8 ms; n = 32: 471 -> 451 ms; n = 26 would LOSE (8.5 -> 9.9 ms,
-    // the host becomes the bottleneck), hence the threshold.  QSIM_SCHED_LOCAL / QSIM_SCHED_LOOKAHEAD override.
-    const int size_class = n - (f32 ? 1 : 0); // log2 of the state size in 16-byte units
-    if (fuse >= 3 && size_class >= 28) {
-        c.local_iters = 3;
-        c.lookahead = 1;
-        if (tile_max_ops == 32) { c.tile_max_ops = 24; c.tail_max_ops = 32; } // 32 = the option's default, i.e. not chosen by the caller
-    }
-    return c;
+    return engine_sched_config(n, fuse, tile_bits, tile_low_bits, tile_max_ops, pad_from, f32, initial_support);
 }
 
 static inline void to_m2(const FusedOp &op, M2 &u) {
@@ -1573,6 +1553,21 @@ extern "C" int qsim_choose_schedule(qsim_state *s, const qsim_circuit *c) {
     return QSIM_OK;
 }
 
+// The same choice for a run that finds the state with exactly this support (what qsim_flush will key its lookup with: all ones
+// for a dense state, 0 fresh from a reset, the mask of qsim_set_support after a sparse exchange).
+extern "C" int qsim_choose_schedule_for(qsim_state *s, const qsim_circuit *c, uint64_t support) {
+    if (!s || !c) return fail(QSIM_ERR_ARG, "NULL argument");
+    if (c->num_q != s->n) return fail(QSIM_ERR_ARG, "circuit has %d qubits, state has %d", c->num_q, s->n);
+    const int rc = qsim_flush(s);
+    if (rc) return rc;
+    const uint64_t nmask = s->n >= 64 ? ~0ULL : ((1ULL << s->n) - 1ULL);
+    if (!s->sparse_start || (support & nmask) == nmask) support = ~0ULL;
+    else support &= nmask;
+    const SchedConfig scfg = sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32, support);
+    choose_schedule(s, c, scfg, nullptr);
+    return QSIM_OK;
+}
+
 // ---- measured pass geometry -------------------------------------------------------------------------------------------
 // Plans the circuit exactly as qsim_run_circuit + qsim_flush would and, for every tile pass whose geometry is not in the
 // table yet, times the pass (its real blocks, on whatever the state buffer holds) under candidate orders of its high
@@ -1584,16 +1579,26 @@ extern "C" int qsim_tune_circuit(qsim_state *s, const qsim_circuit *c, int max_c
     return qsim_tune_circuit_from(s, c, max_candidates, budget_ms, rep, 0);
 }
 
+extern "C" int qsim_tune_circuit_support(qsim_state *s, const qsim_circuit *c, int max_candidates, double budget_ms, qsim_tune_report *rep, uint64_t support);
 extern "C" int qsim_tune_circuit_from(qsim_state *s, const qsim_circuit *c, int max_candidates, double budget_ms, qsim_tune_report *rep,
                                       int dense_start) {
+    return qsim_tune_circuit_support(s, c, max_candidates, budget_ms, rep, dense_start ? ~0ULL : 0);
+}
+
+extern "C" int qsim_tune_circuit_support(qsim_state *s, const qsim_circuit *c, int max_candidates, double budget_ms, qsim_tune_report *rep, uint64_t support) {
     if (!s || !c) return fail(QSIM_ERR_ARG, "NULL argument");
     if (c->num_q != s->n) return fail(QSIM_ERR_ARG, "circuit has %d qubits, state has %d", c->num_q, s->n);
     if (max_candidates < 1) max_candidates = 1;
     int rc = qsim_sync(s);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(s->device));
+    {
+        const uint64_t nmask = s->n >= 64 ? ~0ULL : ((1ULL << s->n) - 1ULL);
+        if (!s->sparse_start || (support & nmask) == nmask) support = ~0ULL;
+        else support &= nmask;
+    }
     SchedConfig scfg = sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32,
-                                    s->sparse_start && !dense_start ? 0 : ~0ULL); // by default the run that follows starts from the reset this call ends with
+                                    support); // 0: the run that follows starts from the reset this call ends with
     // Which way to schedule THIS circuit (SchedConfig::commute) is decided first; its passes are the ones measured below.
     std::vector<Pass> passes;
     choose_schedule(s, c, scfg, &passes);
@@ -1744,10 +1749,15 @@ extern "C" void qsim_tune_table_clear(void) {
     g_wisdom_epoch++;
 }
 
+extern "C" int qsim_plan_circuit_from(const qsim_circuit *c, int fuse, int tile_bits, int tile_low_bits, uint64_t initial_support, qsim_stats *out);
 extern "C" int qsim_plan_circuit(const qsim_circuit *c, int fuse, int tile_bits, int tile_low_bits, qsim_stats *out) {
+    return qsim_plan_circuit_from(c, fuse, tile_bits, tile_low_bits, 0, out);
+}
+
+extern "C" int qsim_plan_circuit_from(const qsim_circuit *c, int fuse, int tile_bits, int tile_low_bits, uint64_t initial_support, qsim_stats *out) {
     if (!c || !out) return fail(QSIM_ERR_ARG, "NULL argument");
     if (fuse < 0 || fuse > 3) return fail(QSIM_ERR_ARG, "fuse level %d not in 0..3", fuse);
-    Scheduler sched(sched_config(c->num_q, fuse, tile_bits, tile_low_bits, 32));
+    Scheduler sched(sched_config(c->num_q, fuse, tile_bits, tile_low_bits, 32, 10, false, initial_support));
     feed(sched, c);
     std::vector<Pass> passes;
     sched.finish(passes);

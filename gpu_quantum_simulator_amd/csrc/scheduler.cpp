@@ -135,22 +135,50 @@ void apply_sched_env(const SchedEnv &e, SchedConfig &cfg) {
 
 Scheduler::Scheduler(const SchedConfig &cfg) : cfg_(cfg), open_(cfg.n > 0 ? cfg.n : 0, -1) { apply_sched_env(read_sched_env(), cfg_); }
 
+SchedConfig engine_sched_config(int n, int fuse, int tile_bits, int tile_low_bits, int tile_max_ops, int pad_from, bool f32, uint64_t initial_support) {
+    SchedConfig c;
+    c.pad_from = pad_from;
+    c.initial_support = initial_support; // 0: the run starts from a reset (what the planning entry points assume)
+    c.n = n; c.fuse = fuse; c.tile_bits = tile_bits; c.tile_low_bits = tile_low_bits; c.tile_max_ops = tile_max_ops;
+    // The pass-set local search (SchedConfig::local_iters with one pass of lookahead) costs ~1.5 ms of host time per
+    // pass.  Passes are launched as they are produced, so the search is free once a pass runs longer than that on the
+    // GPU: from 4 GiB of state (n = 28 fp64: 1.9 ms per pass).  Since the row-class form of the sparse blocks (one LDS
+    // read per amplitude) most passes are bound by their memory time again, so one pass less is ~7 ms less at n = 30
+    // (round 1: the fuller passes were LDS-bound and the total did not move).  With the search on, a pass is capped at
+    // 24 clusters (5-6 merged blocks): ~1.6 + 0.8 ms per block then stays under the pass's ~6.8 ms of memory time.
+    // Twelve seeded 1000-gate circuits at n = 30: 204 passes without the search, 188 with it (191 / 193 with two /
+    // three passes of lookahead, which also cost more host time, so one it is).  n = 30 bench circuit: 16 passes /
+    // 119.7 ms without, 15 / 115.5 ms with; n = 28: 31.1 -> 29.8 ms; n = 32: 471 -> 451 ms; n = 26 would LOSE (8.5 -> 9.9 ms,
+    // the host becomes the bottleneck), hence the threshold.  QSIM_SCHED_LOCAL / QSIM_SCHED_LOOKAHEAD override.
+    const int size_class = n - (f32 ? 1 : 0); // log2 of the state size in 16-byte units
+    if (fuse >= 3 && size_class >= 28) {
+        c.local_iters = 3;
+        c.lookahead = 1;
+        if (tile_max_ops == 32) { c.tile_max_ops = 24; c.tail_max_ops = 32; } // 32 = the option's default, i.e. not chosen by the caller
+    }
+    return c;
+}
+
 void Scheduler::close(int idx) {
     if (idx < 0) return;
     FusedOp &op = pool_[idx];
     open_[op.q_hi] = -1;
     if (op.kind == OP_G2) open_[op.q_lo] = -1;
-    if (!op.is_identity()) closed_.push_back(op);
+    if (!op.is_identity()) {
+        closed_.push_back(op);
+        if (cfg_.track) closed_src_.push_back(std::move(pool_src_[(size_t)idx]));
+    }
     op.kind = 0;
 }
 
 void Scheduler::add_1q(const cd U[4], int q) {
-    gates_++;
+    const uint32_t g = (uint32_t)gates_++;
     if (cfg_.fuse == 0) {
         FusedOp op;
         op.kind = OP_G1; op.q_hi = q; op.gates = 1;
         std::copy(U, U + 4, op.m);
         closed_.push_back(op);
+        if (cfg_.track) closed_src_.push_back({g});
         return;
     }
     const int idx = open_[q];
@@ -159,6 +187,7 @@ void Scheduler::add_1q(const cd U[4], int q) {
         op.kind = OP_G1; op.q_hi = q; op.gates = 1;
         std::copy(U, U + 4, op.m);
         pool_.push_back(op);
+        if (cfg_.track) pool_src_.push_back({g});
         open_[q] = (int)pool_.size() - 1;
         return;
     }
@@ -172,11 +201,13 @@ void Scheduler::add_1q(const cd U[4], int q) {
         op.kind = OP_G1; op.q_hi = q; op.gates = 1;
         std::copy(U, U + 4, op.m);
         pool_.push_back(op);
+        if (cfg_.track) pool_src_.push_back({g});
         open_[q] = (int)pool_.size() - 1;
         return;
     }
     FusedOp &c = pool_[idx];
     c.gates++;
+    if (cfg_.track) pool_src_[(size_t)idx].push_back(g);
     if (c.kind == OP_G1) {
         mul2(U, c.m, c.m); // later gate multiplies from the left
     } else {
@@ -188,39 +219,42 @@ void Scheduler::add_1q(const cd U[4], int q) {
 }
 
 void Scheduler::add_cx(int control, int target) {
-    gates_++;
+    const uint32_t g = (uint32_t)gates_++;
     if (control == target) return; // quantum_simulator.c:99: a silent no-op
     if (cfg_.fuse <= 1) {
         if (cfg_.fuse == 1) { close(open_[control]); close(open_[target]); }
         FusedOp op;
         op.kind = OP_CX; op.q_hi = control; op.q_lo = target; op.gates = 1;
         closed_.push_back(op);
+        if (cfg_.track) closed_src_.push_back({g});
         return;
     }
     cd m[16];
     cx4(control > target, m);
-    fold_2q(m, std::max(control, target), std::min(control, target), 1);
+    fold_2q(m, std::max(control, target), std::min(control, target), 1, g);
 }
 
 void Scheduler::add_2q(const cd U[16], int q_hi, int q_lo) {
-    gates_++;
+    const uint32_t g = (uint32_t)gates_++;
     if (cfg_.fuse <= 1) {
         if (cfg_.fuse == 1) { close(open_[q_hi]); close(open_[q_lo]); }
         FusedOp op;
         op.kind = OP_G2; op.q_hi = q_hi; op.q_lo = q_lo; op.gates = 1;
         std::copy(U, U + 16, op.m);
         closed_.push_back(op);
+        if (cfg_.track) closed_src_.push_back({g});
         return;
     }
-    fold_2q(U, q_hi, q_lo, 1);
+    fold_2q(U, q_hi, q_lo, 1, g);
 }
 
-void Scheduler::fold_2q(const cd U[16], int q_hi, int q_lo, uint32_t gates) {
+void Scheduler::fold_2q(const cd U[16], int q_hi, int q_lo, uint32_t gates, uint32_t g) {
     int ia = open_[q_hi], ib = open_[q_lo];
     if (ia >= 0 && ia == ib) { // the pair is already one cluster: keep folding
         FusedOp &c = pool_[ia];
         mul4(U, c.m, c.m);
         c.gates += gates;
+        if (cfg_.track) pool_src_[(size_t)ia].push_back(g);
         return;
     }
     // a cluster shared with a third qubit has to run first
@@ -247,14 +281,23 @@ void Scheduler::fold_2q(const cd U[16], int q_hi, int q_lo, uint32_t gates) {
     if (ia >= 0) pool_[ia].kind = 0;
     if (ib >= 0) pool_[ib].kind = 0;
     pool_.push_back(op);
+    if (cfg_.track) {
+        std::vector<uint32_t> src;
+        if (ia >= 0) src = std::move(pool_src_[(size_t)ia]);
+        if (ib >= 0) src.insert(src.end(), pool_src_[(size_t)ib].begin(), pool_src_[(size_t)ib].end());
+        src.push_back(g);
+        pool_src_.push_back(std::move(src));
+    }
     open_[q_hi] = open_[q_lo] = (int)pool_.size() - 1;
 }
 
 void Scheduler::finish(const PassSink &sink) {
     for (int q = 0; q < cfg_.n; q++) close(open_[q]);
     pool_.clear();
+    pool_src_.clear();
     build_passes(sink);
     closed_.clear();
+    closed_src_.clear();
 }
 
 void Scheduler::finish(std::vector<Pass> &out) {
@@ -423,6 +466,7 @@ static TileBlock to_block(const FusedOp &op, uint64_t inside) {
 void Scheduler::single_op_pass(const FusedOp &op, const PassSink &sink) const {
     const double S = 16.0 * (double)(1ULL << cfg_.n); // bytes of state
     Pass p;
+    p.src = cur_src_;
     p.ops.push_back(op);
     if (op.kind == OP_G1) {
         if (op.is_identity()) return;
@@ -476,6 +520,7 @@ uint64_t Scheduler::tile_pass(const std::vector<FusedOp> &ops, uint64_t hset, co
     const int L = std::min(cfg_.tile_low_bits, B);
     const uint64_t lowmask = (1ULL << L) - 1ULL;
     Pass p;
+    p.src = cur_src_;
     p.kclass = QSIM_K_TILE;
     p.bytes = 32.0 * (double)(1ULL << cfg_.n);
     // `hset`: the high qubits the blocks NEED in the tile.  Qubits a block is merely block-diagonal in may stay outside
@@ -550,8 +595,13 @@ uint64_t Scheduler::tile_pass(const std::vector<FusedOp> &ops, uint64_t hset, co
 }
 
 void Scheduler::build_passes(const PassSink &sink) {
+    auto note = [&](const std::vector<long> &idx) { // the gates behind the clusters of the pass about to be emitted
+        cur_src_.clear();
+        if (!cfg_.track) return;
+        for (long i : idx) cur_src_.insert(cur_src_.end(), closed_src_[(size_t)i].begin(), closed_src_[(size_t)i].end());
+    };
     if (cfg_.fuse <= 2) {
-        for (const FusedOp &op : closed_) single_op_pass(op, sink);
+        for (size_t i = 0; i < closed_.size(); i++) { note({(long)i}); single_op_pass(closed_[i], sink); }
         return;
     }
     const int B = std::min(cfg_.tile_bits, cfg_.n);
@@ -730,6 +780,7 @@ void Scheduler::build_passes(const PassSink &sink) {
             if (picks0.size() >= 2 && (double)picks0.size() >= cfg_.cheap_margin * (double)cfg_.tile_max_ops * share) {
                 std::sort(picks0.begin(), picks0.end());
                 for (long i : picks0) { group.push_back(closed_[(size_t)i]); done[(size_t)i] = 1; }
+                note(picks0);
                 note_tile(tile_pass(group, h0, sink, support));
                 continue;
             }
@@ -800,6 +851,7 @@ void Scheduler::build_passes(const PassSink &sink) {
             group.push_back(closed_[(size_t)i]);
             done[(size_t)i] = 1;
         }
+        note(group.empty() ? std::vector<long>{(long)first} : best_picks);
         if (group.empty()) { // cannot happen while kmax >= 2; keep the scheduler total anyway
             single_op_pass(closed_[first], sink);
             done[first] = 1;

@@ -105,6 +105,7 @@ struct Pass {
         for (const TileBlock &b : blocks) g += b.gates;
         return g;
     }
+    std::vector<uint32_t> src; // SchedConfig::track: the gates folded into this pass, by their order of arrival at the scheduler (0, 1, ...)
     double bytes = 0;         // algorithmic bytes this pass must move when it sweeps the whole register
     double visited = 1.0;     // ... times this: the fraction of the register inside the state's support after the pass (tile passes of a run that starts from a reset, SchedConfig::initial_support)
     bool diag_full = false;   // QSIM_K_PHASE executed over every amplitude (d0 != 1 or q < 2)
@@ -138,7 +139,13 @@ struct SchedConfig {
     // seeded 1000-gate circuits at n = 30: 892 -> 835 ms in total) but the greedy packing does not use it well on every
     // circuit, so the planning step (qsim_tune_circuit) schedules both ways and keeps the cheaper one for that circuit.
     int commute = 1;
+    int track = 0; // 1: every pass lists the gates it absorbed (Pass::src) — the shard planner asks which gates a segment's last pass holds
 };
+
+// The configuration qsim_flush schedules with for a state of n qubits (options as given by the caller; the search settings
+// follow the size of the state, see the comment in scheduler.cpp).
+SchedConfig engine_sched_config(int n, int fuse, int tile_bits, int tile_low_bits, int tile_max_ops, int pad_from = 10, bool f32 = false,
+                                uint64_t initial_support = 0);
 
 // The QSIM_SCHED_* environment variables override the search parameters for experiments (tools/).
 // They are not part of the API and change the pass count, never the result — but they DO shape the schedule, so the
@@ -182,9 +189,11 @@ class Scheduler {
     std::vector<FusedOp> pool_;   // open clusters
     std::vector<int> open_;       // per qubit: index into pool_, or -1
     std::vector<FusedOp> closed_; // fused ops in a valid execution order
+    std::vector<std::vector<uint32_t>> pool_src_, closed_src_; // SchedConfig::track: the gates behind pool_[i] / closed_[i]
+    mutable std::vector<uint32_t> cur_src_;                     // ... and behind the pass being emitted
 
     void close(int idx);
-    void fold_2q(const cd U[16], int q_hi, int q_lo, uint32_t gates);
+    void fold_2q(const cd U[16], int q_hi, int q_lo, uint32_t gates, uint32_t gate_index);
     void build_passes(const PassSink &sink);
     void single_op_pass(const FusedOp &op, const PassSink &sink) const;
     // prefer: index bits free tile slots are filled from first (the state's support while it is partial); returns the tile's qubit mask

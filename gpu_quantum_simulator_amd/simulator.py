@@ -101,9 +101,11 @@ class Circuit:
             return ("cx", q0.value, q1.value)
         return ("u2", q0.value, q1.value, u.view(np.complex128).reshape(4, 4).copy())
 
-    def plan(self, fuse: int = 3, tile_bits: int = 12, tile_low_bits: int = 3) -> dict:
+    def plan(self, fuse: int = 3, tile_bits: int = 12, tile_low_bits: int = 3, initial_support: int = 0) -> dict:
+        """Launches and algorithmic bytes of the schedule (host only).  initial_support: index bits that may be 1 in the state
+        the circuit finds (0: fresh from a reset; all ones: dense)."""
         st = QsimStats()
-        check(_lib.load().qsim_plan_circuit(self._h, fuse, tile_bits, tile_low_bits, byref(st)))
+        check(_lib.load().qsim_plan_circuit_from(self._h, fuse, tile_bits, tile_low_bits, initial_support, byref(st)))
         return st.as_dict()
 
     def schedule(self, fuse: int = 3, tile_bits: int = 12, tile_low_bits: int = 3, tile_max_ops: int = 32) -> list:
@@ -377,6 +379,10 @@ class Cluster:
         self._check(lib.qsim_cluster_reset(self._h))
         self._check(lib.qsim_cluster_run_circuit(self._h, circuit._h))
         self._check(lib.qsim_cluster_sync(self._h))
+
+    def plan(self, circuit: Circuit, max_candidates: int = 1, budget_ms: float = 0.0) -> None:
+        """qsim_cluster_plan: schedule choice (and, with max_candidates > 1, measured tile-bit orders) for every shard's local steps."""
+        self._check(_lib.load().qsim_cluster_plan(self._h, circuit._h, max_candidates, budget_ms))
 
     def read(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
         if count is None:

@@ -195,6 +195,10 @@ int qsim_choose_schedule(qsim_state *s, const qsim_circuit *circuit);
  * run differs in its first passes (QSIM_OPT_SPARSE_START), e.g. a shard's local gates after its first exchange. */
 int qsim_tune_circuit_from(qsim_state *s, const qsim_circuit *circuit, int max_candidates, double budget_ms, qsim_tune_report *report,
                            int dense_start);
+/* Both for a run that finds the state with exactly the support `support` (index bits that may be 1: 0 fresh from a reset, all
+ * ones dense, the mask given to qsim_set_support after a sparse exchange): a shard's local steps between exchanges. */
+int qsim_choose_schedule_for(qsim_state *s, const qsim_circuit *circuit, uint64_t support);
+int qsim_tune_circuit_support(qsim_state *s, const qsim_circuit *circuit, int max_candidates, double budget_ms, qsim_tune_report *report, uint64_t support);
 long qsim_tune_table_size(void);
 void qsim_tune_table_clear(void);
 int qsim_tune_table_save(const char *path);  /* text, one geometry per line */
@@ -272,6 +276,11 @@ int qsim_cluster_set_option(qsim_cluster *c, int option, long value);
 int qsim_cluster_reset(qsim_cluster *c); /* |0...0>, identity qubit map */
 int qsim_cluster_run_circuit(qsim_cluster *c, const qsim_circuit *circuit);
 int qsim_cluster_sync(qsim_cluster *c);
+/* Planning for a circuit the cluster will run (repeatedly): the shard plan is built and kept, and every shard's local steps go
+ * through the schedule choice of qsim_choose_schedule — and, with max_candidates > 1, through the measured tile-bit orders of
+ * qsim_tune_circuit (budget_ms for all shards together, 0 = unbounded) — each for the support the shard will have at that
+ * point of the run.  Outside any timed region; results never depend on it.  Leaves the cluster reset. */
+int qsim_cluster_plan(qsim_cluster *c, const qsim_circuit *circuit, int max_candidates, double budget_ms);
 int qsim_cluster_read(qsim_cluster *c, uint64_t logical_first, uint64_t count, double *out_re_im);
 int qsim_cluster_norm2(qsim_cluster *c, double *out);
 /* qsim_sample for a sharded state: basis indices in LOGICAL order for random numbers in [0,1] (measurement(),
@@ -391,6 +400,9 @@ int qsim_gate_matrix(const char *token, double *U);
 /* Runs the fusion scheduler on a circuit and reports launches and algorithmic bytes per kernel class
  * for a state of num_q qubits at the given fuse level.  Used by tests and by the planner. */
 int qsim_plan_circuit(const qsim_circuit *c, int fuse, int tile_bits, int tile_low_bits, qsim_stats *out);
+/* The same for a run that does not start from a reset: initial_support = index bits that may be 1 in the state the circuit
+ * finds (all ones: a dense state, e.g. a shard after its second exchange; 0: fresh from a reset, what qsim_plan_circuit assumes). */
+int qsim_plan_circuit_from(const qsim_circuit *c, int fuse, int tile_bits, int tile_low_bits, uint64_t initial_support, qsim_stats *out);
 /* Same scheduler, op by op: calls `cb` for every fused block in launch order with the pass it belongs to, the
  * kernel class of that pass, the block kind (QSIM_GATE_U1 / _CX / _U2 .. _U7 by qubit count), its qubits (most
  * significant first; CX: control, target) and its matrix (2^nq x 2^nq complex, row-major; NULL for CX).  A block of a

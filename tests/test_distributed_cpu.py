@@ -140,10 +140,13 @@ def test_gloo_ranks_equal_oracle(oracle, tmp_path, world):
 @pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("n,depth,seed,vocab", [(8, 300, 11, "all"), (12, 600, 12, "all"), (16, 800, 13, "clifford_t"),
                                                 (30, 1000, 20240147, "all")])
-def test_cpp_planner_equals_python_restatement(world, n, depth, seed, vocab):
+def test_cpp_planner_equals_python_restatement(world, n, depth, seed, vocab, monkeypatch):
     """libqsim's planner (csrc/dist.cpp: the product path of both the C host and distributed.py) against the
     independent pure-Python restatement in tests/py_shard_plan.py: same exchanges, same final qubit map, and the same
-    per-rank local ops on every rank."""
+    per-rank local ops on every rank.  The restatement covers the planner proper (which gates can run, Belady eviction,
+    the two placement policies); the hand-over of a segment's small last pass to the next segment (small_tail, which asks
+    the engine's own scheduler) is switched off for the comparison and tested on its own below."""
+    monkeypatch.setenv("QSIM_SHARD_TAIL", "0")
     gates = normalize_gates(circuits.random_gates(n, depth, seed, vocab), gate_matrix)
     p = world.bit_length() - 1
     for rank in sorted({0, 1, world - 1}):
@@ -164,6 +167,58 @@ def test_cpp_planner_equals_python_restatement(world, n, depth, seed, vocab):
                         assert x[1] == y[1] and np.array_equal(x[2], y[2])
                     else:
                         assert x[1] == y[1]
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_small_last_pass_waits_for_the_exchange(oracle, tmp_path, world, monkeypatch):
+    """csrc/dist.cpp small_tail: a segment's last pass, when the engine's scheduler would fill it with only a handful of
+    gates, is handed on to the segment after the exchange.  The plan stays a valid execution order (CPU shards equal the
+    oracle), no gate is lost or duplicated, and on the bench circuit the shards sweep their part of the register less often."""
+    n = 14
+    gates = circuits.random_gates(n, 900, 77, "all")
+    want = _oracle_state(oracle, tmp_path, n, gates)
+    norm = normalize_gates(gates, gate_matrix)
+    p = world.bit_length() - 1
+    counts = {}
+    for tail in ("0", "24"):
+        monkeypatch.setenv("QSIM_SHARD_TAIL", tail)
+        vc = VirtualCluster(n, world, gates, shard_factory=CpuShard)
+        vc.run()
+        assert np.max(np.abs(vc.gather_logical() - want)) < TOL
+        pl = vc.plans[0]
+        # every gate statement appears exactly once over the local steps of a rank that sees them all (scalars equal to 1 and
+        # conditional X gates whose control bit is 0 are dropped per rank, so count on the plan of the all-ones rank)
+        full = ShardPlan(n, p, norm, world - 1)
+        counts[tail] = sum(len(st[1]) for st in full.steps if st[0] == "local")
+    assert counts["0"] == counts["24"]
+    # the n = 30 bench circuit, host only: swept bytes of shard P-1's schedule, with and without the hand-over
+    from gpu_quantum_simulator_amd import Circuit
+    n = 30
+    norm = normalize_gates(circuits.random_gates(n, 1000, 20240117 + n, "all"), gate_matrix)
+    sweeps = {}
+    for tail in ("0", "24"):
+        monkeypatch.setenv("QSIM_SHARD_TAIL", tail)
+        pl = ShardPlan(n, p, norm, world - 1)
+        m, tot, sup, empty = n - p, 0.0, 0, True
+        for i, st in enumerate(pl.steps):
+            if st[0] == "exchange":
+                ro = pl.handle.exchange_roles(i, world - 1)
+                empty, sup = bool(ro["empty_after"]), ro["new_support"]
+                continue
+            if empty:
+                continue
+            c = Circuit.empty(m)
+            for op in st[1]:
+                if op[0] == "cx":
+                    c.append_cx(op[1], op[2])
+                else:
+                    c.append_1q(op[2] if op[0] == "u1" else [[op[1], 0], [0, op[1]]], op[1] if op[0] == "u1" else 0)
+            tot += c.plan(initial_support=sup)["algorithmic_bytes"] / (32.0 * (1 << m))
+            sup = (1 << m) - 1
+        sweeps[tail] = tot
+    assert sweeps["24"] <= sweeps["0"]
+    if world == 8:
+        assert sweeps["24"] <= sweeps["0"] - 1.0  # 14 -> 12 sweeps of the shard
 
 
 def test_launcher_spawns_ranks_as_children():

@@ -1231,7 +1231,7 @@ def test_flush_pack_last_pass_does_the_relayout(oracle, tmp_path, bits, pingpong
             assert np.max(np.abs(got - want[src])) < TOL, rep
         # blocks steered into a buffer four times the size: block b -> index bits to_bits, plus a constant offset
         to_bits = [n + 1 - j for j in range(k)] if k <= 2 else [n - k + j for j in range(k)]
-        konst = (1 << (n + 1)) if k == 1 else 0
+        konst = (1 << n) if k == 1 else 0
         sim.reset()
         sim.run(c)
         at, fused = sim.flush_pack(bits, big.data_ptr(), to_bits=to_bits, konst=konst)

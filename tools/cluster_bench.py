@@ -1,6 +1,7 @@
 """Overhead of the sharded path itself, links excluded: P virtual shards on ONE device (exchanges = HBM copies)."""
 import sys, time
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from gpu_quantum_simulator_amd import Circuit, Cluster, Simulator, circuits
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 c = Circuit.from_gates(n, circuits.random_gates(n, 1000, 20240117 + n, "all"))
@@ -13,7 +14,9 @@ with Simulator(n) as sim:
     print(f"single      : {dt*1e3:8.2f} ms/iter  launches/iter={sim.stats()['launches']//3}", flush=True)
 for P in (2, 4, 8):
     with Cluster(n, P, devices=[0] * P) as cl:
+        cl.plan(c)  # the schedule choice per shard and local step, like sim.choose_schedule above (host work, outside the clock)
         cl.run(c)
         t0 = time.perf_counter(); cl.run(c); cl.run(c); dt = (time.perf_counter() - t0) / 2
         ex, nb = cl.exchange_stats()
-        print(f"{P} virtual   : {dt*1e3:8.2f} ms/iter  exchanges/iter={ex//3}  GiB moved per shard/iter={nb/3/2**30:.2f}", flush=True)
+        print(f"{P} virtual   : {dt*1e3:8.2f} ms/iter  exchanges/iter={ex//3}  GiB per shard/iter if every block travelled={nb/3/2**30:.2f}  "
+              f"GiB really moved (all shards)/iter={cl.exchange_bytes_moved()/3/2**30:.2f}  packs fused/separate={cl.pack_counts()}", flush=True)

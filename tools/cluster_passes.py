@@ -2,7 +2,8 @@
 and how long each takes.  Usage: python tools/cluster_passes.py [n] [P]"""
 import sys
 from ctypes import byref, c_double, c_int, c_uint64, c_void_p
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from gpu_quantum_simulator_amd import Circuit, Cluster, circuits, _lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 8
@@ -10,6 +11,7 @@ c = Circuit.from_gates(n, circuits.random_gates(n, 1000, 20240117 + n, "all"))
 lib = _lib.load()
 lib.qsim_cluster_shard.restype = c_void_p
 with Cluster(n, P, devices=[0] * P, profile=1) as cl:
+    cl.plan(c)
     cl.run(c)
     shards = [c_void_p(lib.qsim_cluster_shard(cl._h, r)) for r in range(P)]
     for s in shards:

@@ -72,6 +72,8 @@ def parse_args(argv=None):
     ap.add_argument("--tune-candidates", type=int, default=48)
     ap.add_argument("--tune-ms", type=float, default=8000.0, help="wall-time budget of the planning step per register size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-precision32", action="store_true", help="skip the extra fp32 record of the default run")
+    ap.add_argument("--no-one-shot", action="store_true", help="skip the cold figures (bin/qsim as a child process)")
     ap.add_argument("--no-full-sweeps", action="store_true",
                     help="skip the extra steps with QSIM_OPT_SPARSE_START off (profile runs: every launch then is one of the timed kind)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -109,7 +111,7 @@ def host_ram_bytes():
         return 0
 
 
-def cpu_baseline(n, gates, budget_s):
+def cpu_baseline(n, gates, budget_s, min_gates=3):
     """quantum_simulator.c's hot loops (the oracle's restatement of :81-106) on this host, 1 thread, on a bounded
     sample of the same circuit."""
     import ctypes
@@ -139,7 +141,7 @@ def cpu_baseline(n, gates, budget_s):
             u = np.ascontiguousarray(gate_matrix(tok).T.reshape(4))  # symmetric anyway
             L.oracle_apply_1q(sp, n, u.view(np.float64).ctypes.data_as(dp), g[-1])
         done += 1
-        if time.perf_counter() - t0 >= budget_s:
+        if done >= min_gates and time.perf_counter() - t0 >= budget_s:
             break
     dt = time.perf_counter() - t0
     del state
@@ -147,27 +149,122 @@ def cpu_baseline(n, gates, budget_s):
             "sample": f"first {done} gate statements of the same n={n} circuit, {dt:.1f} s, 1 thread, state resident in host RAM"}
 
 
-def exchange_model(depth, vocabulary, ms_per_step_n30, link_gbps=50.0, pack_gbps=5000.0):
-    """What the planner's cost model predicts for the multi-GPU configs of BASELINE.json, computed from the plans alone
-    (host work, no GPU): exchanges, qubits swapped, bytes per rank, exchange time, and the step time that follows when
-    the local passes scale with the shard size from the measured 1-GPU n=30 step."""
+def exchange_model(depth, vocabulary, tile_gbps, ms_per_step_n30, link_gbps=50.0, pack_gbps=5000.0):
+    """What the plans predict for the multi-GPU configs of BASELINE.json, from host work alone (no GPU): per config the
+    passes rank 0's engine will schedule between the exchanges — counted in sweeps of the shard, the sparse first passes
+    by the fraction they visit (ShardPlan.local_sweeps: the very scheduler the engine runs) — priced at the tile kernel's
+    rate measured in THIS run, and the exchanges priced per link: a k-qubit swap puts 2^-k of the shard on each of 2^k - 1
+    links at once, and the blocks of ranks that hold nothing yet stay home.  The re-layout of an exchange rides on the last
+    tile pass in front of it (qsim_flush_pack), so it costs no sweep; `pack_gbps` only prices the exchanges whose last pass
+    cannot take it (none in these plans)."""
     from gpu_quantum_simulator_amd import circuits, gate_matrix
     from gpu_quantum_simulator_amd.distributed import ShardPlan, normalize_gates
     rows = []
     for n, P in ((30, 2), (30, 4), (30, 8), (33, 8)):
         gates = normalize_gates(circuits.random_gates(n, depth, 20240117 + n, vocabulary), gate_matrix)
-        plan = ShardPlan(n, P.bit_length() - 1, gates, 0)
-        nbytes, secs = plan.predict(link_gbps, pack_gbps)
-        local_ms = ms_per_step_n30 * (2.0 ** (n - 30)) / P
-        rows.append({"qubits": n, "ranks": P, "exchanges": plan.exchanges,
-                     "qubits_swapped": [len(st[1]) for st in plan.steps if st[0] == "exchange"],
-                     "bytes_sent_per_rank": nbytes, "predicted_exchange_ms": 1e3 * secs,
-                     "predicted_local_ms": local_ms, "predicted_step_ms": local_ms + 1e3 * secs,
-                     "vs_ideal": (local_ms + 1e3 * secs) / (ms_per_step_n30 * (2.0 ** (n - 30)) / P)})
-    return {"assumptions": {"link_gbps_per_direction": link_gbps, "pack_gbps": pack_gbps,
+        p = P.bit_length() - 1
+        worst = None
+        for rank in sorted({0, P - 1}):  # rank 0 carries the sparse start, the others join at the first exchange
+            ls = ShardPlan(n, p, gates, rank).local_sweeps()
+            if worst is None or ls["sweeps"] > worst["sweeps"]:
+                worst = ls
+        shard_bytes = 16.0 * (1 << (n - p))
+        local_ms = 1e3 * worst["sweeps"] * 2.0 * shard_bytes / (tile_gbps * 1e9)
+        sent = sum(x["blocks_sent"] * x["block_bytes"] for x in worst["exchanges"])
+        xms = sum((1e3 * x["block_bytes"] / (link_gbps * 1e9)) if (x["blocks_sent"] or x["blocks_received"]) else 0.0 for x in worst["exchanges"])
+        ideal = ms_per_step_n30 * (2.0 ** (n - 30)) / P
+        rows.append({"qubits": n, "ranks": P, "exchanges": len(worst["exchanges"]),
+                     "qubits_swapped": [x["qubits"] for x in worst["exchanges"]],
+                     "local_passes": worst["passes"], "local_sweeps_of_the_shard": worst["sweeps"],
+                     "bytes_sent_per_rank": sent, "predicted_exchange_ms": xms,
+                     "predicted_local_ms": local_ms, "predicted_step_ms": local_ms + xms,
+                     "ideal_ms": ideal, "vs_ideal": (local_ms + xms) / ideal})
+    return {"assumptions": {"link_gbps_per_direction": link_gbps, "tile_kernel_gbps_measured_in_this_run": tile_gbps,
                             "note": "xGMI link ~76.8 GB/s per direction peak (7 x ~153 GB/s bidirectional per GPU), 65 % assumed; "
-                                    "no overlap of exchange and local passes; local passes scale with the shard size"},
+                                    "no overlap of exchange and local passes; local term = the shard's own schedule (dense after the "
+                                    "first exchange, sparse before it) at the measured tile-kernel rate; ideal = this run's 1-GPU "
+                                    "n=30 step x 2^(n-30) / ranks"},
             "configs": rows}
+
+
+def run_selfcheck(dist, device, shard_factory=None, require_native=True, qubits=20, depth=400, seed=777):
+    """Before a multi-rank run is timed: a small sharded circuit on the SAME ranks against the oracle (the checker leg,
+    outside any timed region).  Every exchange path the timed run will take — planner, fused re-layout, the library's own
+    RCCL send/recv, support bookkeeping — has to reproduce quantum_simulator.c's amplitudes within 1e-10, on every rank's
+    data, or the bench stops.  Returns the record for the JSON line; raises SystemExit(3) on every rank on a mismatch."""
+    import tempfile
+
+    import numpy as np
+    import torch
+    from gpu_quantum_simulator_amd import circuits
+    from gpu_quantum_simulator_amd.distributed import ShardedSimulator
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = max(qubits, (world.bit_length() - 1) + 12)
+    gates = circuits.random_gates(n, depth, seed, "all")
+    sim = ShardedSimulator(n, gates, device=device, shard_factory=shard_factory)
+    for _ in range(2):  # the second step starts from a used state and replays cached plans
+        sim.run_step()
+    got = sim.gather_logical()
+    norm2 = sim.norm2()
+    rec = {"qubits": n, "gates": depth, "exchanges": sim.plan.exchanges, "exchange_backend": sim.exchange_backend,
+           "tolerance": 1e-10, "norm2": norm2}
+    if hasattr(sim.shard, "comm") and sim.shard.comm is not None:
+        rec["relayouts_fused_separate"] = list(sim.shard.comm.pack_counts())
+    ok = 1
+    if rank == 0:
+        from oracle import oracle  # the checker
+        oracle.build(with_reference=False)
+        with tempfile.TemporaryDirectory() as d:
+            path = circuits.write_qasm(os.path.join(d, "selfcheck.qasm"), n, gates)
+            _, want, _, _ = oracle.run_qasm(path)
+        rec["max_abs_err"] = float(np.max(np.abs(got - want)))
+        if not (rec["max_abs_err"] < 1e-10 and abs(norm2 - 1.0) < 1e-10):
+            ok = 0
+        if require_native and world > 1 and sim.exchange_backend != "rccl-native":
+            ok = 0
+            rec["error"] = "the library's own RCCL communicator is not in use"
+    sim.close()
+    flag = torch.tensor([ok], dtype=torch.int32)
+    if dist.get_backend() == "nccl":
+        flag = flag.cuda()
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    rec["passed"] = bool(int(flag.item()))
+    if not rec["passed"]:
+        if rank == 0:
+            sys.stderr.write("bench.py: sharded self-check FAILED: " + json.dumps(rec) + "\n")
+        dist.barrier()
+        raise SystemExit(3)
+    return rec
+
+
+def one_shot_cli(n, gates):
+    """The reference's own protocol (quantum_simulator.c:143,244-248; tester.bash:12): ONE process, ONE circuit, the printed
+    seconds run from the header to the last gate.  `bin/qsim <file> 1` as a child process of this one — fresh process, no
+    wisdom file, no planning step: allocation, |0...0>, scheduling, block preparation, uploads and every pass are inside
+    the printed time (only the creation of the HIP context, process start-up, is not)."""
+    import subprocess
+    import tempfile
+    from gpu_quantum_simulator_amd import _lib, circuits
+    with tempfile.TemporaryDirectory() as d:
+        path = circuits.write_qasm(os.path.join(d, "one_shot.qasm"), n, gates)
+        env = {k: v for k, v in os.environ.items() if not k.startswith("QSIM_")}
+        env["QSIM_STATS"] = "1"
+        t0 = time.perf_counter()
+        p = subprocess.run([_lib.CLI_PATH, path, "1"], capture_output=True, text=True, env=env, timeout=900)
+        wall = time.perf_counter() - t0
+    rec = {"command": "bin/qsim <file> 1", "exit_code": p.returncode, "process_wall_seconds": wall}
+    try:
+        rec["printed_seconds"] = float(p.stdout.split()[0])
+        rec["value"] = len(gates) / rec["printed_seconds"]
+        rec["unit"] = "gate-applies/s"
+        stats = [ln for ln in p.stderr.splitlines() if ln.startswith("{")]
+        if stats:
+            st = json.loads(stats[-1])
+            rec["launches"] = st.get("launches")
+            rec["breakdown_s"] = {k: st.get(k) for k in ("parse_s", "allocate_s", "schedule_and_launch_s", "wait_s")}
+    except (ValueError, IndexError):
+        rec["error"] = (p.stdout + p.stderr)[-400:]
+    return rec
 
 
 def launch_ranks(args):
@@ -220,10 +317,13 @@ class Bench:
             self.dist.barrier()
             self.torch.cuda.synchronize()
 
-    def measure(self, n, depth, vocabulary, seed, steps, warmup, fuse, opts, probe_q=None, with_1q_probe=False):
-        """Builds the simulator for one register size, runs `warmup` + `steps` timed steps, returns the numbers."""
+    def measure(self, n, depth, vocabulary, seed, steps, warmup, fuse, opts, probe_q=None, with_1q_probe=False, precision=None, cold=False):
+        """Builds the simulator for one register size, runs `warmup` + `steps` timed steps, returns the numbers.
+        cold: before anything is planned, the very first step on the fresh state is timed on its own (empty plan cache,
+        no schedule choice, no measured geometries: what a one-shot run pays), then the second one (cached plan)."""
         from gpu_quantum_simulator_amd import Circuit, Simulator, circuits
         args, dist, torch = self.args, self.dist, self.torch
+        precision = precision or args.precision
         if probe_q is not None:
             gates = circuits.probe_gates(n, probe_q, depth)
             fuse = 0
@@ -237,12 +337,22 @@ class Bench:
             run_step = sim.run_step
         else:
             circuit = Circuit.from_gates(n, gates)
-            sim = Simulator(n, self.local_rank, fuse=fuse, profile=True, precision=args.precision, **opts)
+            sim = Simulator(n, self.local_rank, fuse=fuse, profile=True, precision=precision, **opts)
 
             def run_step():
                 sim.reset()
                 sim.run(circuit)
                 sim.flush()
+
+        cold_ms = None
+        if cold and dist is None:
+            self.fence(sim)
+            cold_ms = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                run_step()
+                self.fence(sim)
+                cold_ms.append(1e3 * (time.perf_counter() - t0))
 
         # Planning, outside the timed region (like parsing): one untuned step is timed for the record, then every pass of
         # the schedule is measured under candidate orders of its tile bits and the best order per geometry is kept
@@ -316,7 +426,8 @@ class Bench:
                 probe[f"q{q}"] = {"kernel": name, "achieved": gbs, "frac": gbs / HBM_PEAK_GBPS, "avg_launch_ms": k[name]["ms"] / 6}
 
         res = {"workload": workload, "n": n, "gates": gates, "elapsed": elapsed, "steps": steps, "stats": stats,
-               "norm2": norm2, "probe": probe, "fuse": fuse, "tuning": tuning, "full_sweeps": full_sweeps}
+               "norm2": norm2, "probe": probe, "fuse": fuse, "tuning": tuning, "full_sweeps": full_sweeps, "cold_ms": cold_ms,
+               "precision": precision, "vocabulary": vocabulary}
         if dist is not None:
             xs, xb = sim.exchange_seconds / steps, sim.exchange_bytes / steps
             res["exchange"] = {"per_step": sim.plan.exchanges,
@@ -354,6 +465,7 @@ def main():
     if args.precision == 32 and (b.world > 1 or args.force_sharded):
         sys.exit("--precision 32 is single-GPU only (shards and clusters are fp64)")
     b.setup()
+    selfcheck = run_selfcheck(b.dist, b.local_rank) if b.dist is not None else None
     if args.wisdom and os.path.exists(args.wisdom):
         from gpu_quantum_simulator_amd import _lib as _qlib
         _qlib.load().qsim_tune_table_load(args.wisdom.encode())
@@ -363,8 +475,10 @@ def main():
     opts = {k: v for k, v in (("tile_bits", args.tile_bits), ("tile_low_bits", args.tile_low_bits),
                               ("tile_max_ops", args.tile_max_ops), ("grid_cap", args.grid_cap),
                               ("tile_threads", args.tile_threads), ("pingpong", args.pingpong)) if v is not None}
+    default_workload = (args.precision == 64 and args.probe is None and n == 30 and args.depth == 1000 and args.fuse == 3 and args.gpus == 1
+                        and not opts and args.vocabulary == "all" and b.dist is None)
     head = b.measure(n, args.depth, args.vocabulary, seed, args.steps, args.warmup, args.fuse, opts,
-                     probe_q=args.probe, with_1q_probe=True)
+                     probe_q=args.probe, with_1q_probe=True, cold=default_workload and not args.wisdom and not args.no_one_shot)
 
     # other register sizes, same generator and defaults (north_star: n = 24/28/30/32)
     sizes = []
@@ -373,11 +487,22 @@ def main():
         weak = args.qubits + int(round(math.log2(b.world)))  # the same shard size as the 1-GPU headline (n=33 on 8 GPUs)
         if b.world > 1 and weak not in want:
             want.append(weak)
-        for m in want:
-            if m == n or m - int(round(math.log2(b.world))) < 14:
+        rows = [(m, args.vocabulary) for m in want]
+        if b.world == 1 and 28 in want and args.vocabulary == "all":
+            rows.insert(rows.index((28, "all")) + 1, (28, "clifford_t"))  # BASELINE configs[2] exactly: random Clifford+T, n=28, depth 1000
+        for m, vocab in rows:
+            if (m == n and vocab == args.vocabulary) or m - int(round(math.log2(b.world))) < 14:
                 continue
-            r = b.measure(m, args.depth, args.vocabulary, 20240117 + m, args.size_steps, 1, args.fuse, opts)
+            r = b.measure(m, args.depth, vocab, 20240117 + m, args.size_steps, 1, args.fuse, opts)
             sizes.append(r)
+
+    # the fp32 state of the reference's CUDA variants (quantum_simulator_naive.cu:72-95,145-149) on the same circuit: an extra
+    # record beside the fp64 headline, never the headline itself
+    f32 = None
+    if default_workload and not args.no_precision32:
+        saved = args.precision
+        f32 = b.measure(n, args.depth, args.vocabulary, seed, max(2, args.size_steps), 1, args.fuse, opts, precision=32)
+        args.precision = saved
 
     if args.wisdom and b.rank == 0:
         from gpu_quantum_simulator_amd import _lib as _qlib
@@ -388,9 +513,7 @@ def main():
         value = args.depth * args.steps / head["elapsed"]
         roof = Bench.roofline_of(stats)
         if roof:
-            default = (args.precision == 64 and args.probe is None and n == 30 and args.depth == 1000 and head["fuse"] == 3
-                       and args.gpus == 1 and not opts and args.vocabulary == "all")
-            roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"], default)
+            roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"], default_workload)
         total_kernel_ms = sum(v["ms"] for v in stats["kernels"].values())
         out = {
             "metric": "gate-applies/sec", "value": value, "unit": "gate-applies/s", "n_gpus": args.gpus,
@@ -416,11 +539,32 @@ def main():
                                    "tile_bytes_vs_full_sweeps": swept, "with_full_sweeps": head["full_sweeps"]}
         if "exchange" in head:
             out["exchange"] = head["exchange"]
+        if selfcheck is not None:
+            out["selfcheck"] = selfcheck
+        if default_workload and not args.no_one_shot:
+            cold = head.get("cold_ms")
+            out["one_shot"] = {"note": "what ONE run of the drop-in costs, the reference's protocol (quantum_simulator.c:143,244-248, "
+                                       "tester.bash:12): no planning step, no wisdom file, plan cache empty; `value` above is the steady "
+                                       "state of a circuit that runs again and again (cached plan, chosen schedule, measured tile-bit orders)",
+                               "cli": one_shot_cli(n, head["gates"]),
+                               "in_process_first_step_ms": cold[0] if cold else None,
+                               "in_process_first_step_value": (args.depth / (cold[0] * 1e-3)) if cold else None,
+                               "in_process_second_step_ms": cold[1] if cold else None}
+        if f32 is not None:
+            rf32 = Bench.roofline_of(f32["stats"])
+            out["precision32"] = {"dtype": "f32", "workload": f32["workload"], "state_bytes": 8 << n,
+                                  "value": args.depth * f32["steps"] / f32["elapsed"], "unit": "gate-applies/s",
+                                  "ms_per_step": 1e3 * f32["elapsed"] / f32["steps"], "steps": f32["steps"],
+                                  "launches_per_step": f32["stats"]["launches"] / f32["steps"], "norm2": f32["norm2"],
+                                  "with_full_sweeps": f32.get("full_sweeps"), "geometry_planning": f32["tuning"],
+                                  "roofline": None if rf32 is None else {k: rf32[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "peak", "unit", "bound")},
+                                  "note": "fp32 complex AoS state (float2), the precision of quantum_simulator_naive.cu:72-95,145-149; agrees with "
+                                          "the fp64 oracle to fp32 rounding (tests/test_gpu_fp32.py, 2e-5), not to 1e-10: never the headline"}
         cpu = not args.no_cpu_baseline and args.gpus == 1 and b.dist is None
         if cpu:
             out["cpu_baseline"] = cpu_baseline(n, head["gates"], args.cpu_seconds)
-        if cpu and args.probe is None and n == 30:
-            out["exchange_model"] = exchange_model(args.depth, args.vocabulary, ms_per_step)
+        if cpu and args.probe is None and n == 30 and roof and roof["kernel"] == "tile":
+            out["exchange_model"] = exchange_model(args.depth, args.vocabulary, roof["achieved"], ms_per_step)
         if sizes:
             table = []
             for r in sizes:
@@ -430,14 +574,15 @@ def main():
                        "ms_per_step": 1e3 * r["elapsed"] / r["steps"], "steps": r["steps"],
                        "launches_per_step": r["stats"]["launches"] / r["steps"], "norm2": r["norm2"],
                        "geometry_planning": r["tuning"], "with_full_sweeps": r.get("full_sweeps"),
-                       "roofline": None if rf is None else {k: rf[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms")}}
+                       "roofline": None if rf is None else {k: rf[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "peak", "unit", "bound")}}
                 if (16 << r["n"]) <= (256 << 20) and row["roofline"]:
                     row["roofline"]["note"] = "the state fits the 256 MiB Infinity Cache: passes run from cache, the HBM roofline does not bound them"
                 if "exchange" in r:
                     row["exchange"] = r["exchange"]
                 if cpu:
-                    # ~10 s of CPU work per size: about 170 gates at n=24, 10 at n=28, 1 at n=32 (one gate there takes longer)
-                    row["cpu_baseline"] = cpu_baseline(r["n"], r["gates"], 10.0 if r["n"] < 31 else 1.0)
+                    # ~10 s of CPU work per size: about 170 gates at n=24, 10 at n=28; at n=32 one gate takes ~6 s: three of them
+                    if r["vocabulary"] == args.vocabulary:
+                        row["cpu_baseline"] = cpu_baseline(r["n"], r["gates"], 10.0 if r["n"] < 31 else 1.0, min_gates=3)
                 table.append(row)
             out["sizes"] = table
         print(json.dumps(out), flush=True)

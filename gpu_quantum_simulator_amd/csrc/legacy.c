@@ -81,6 +81,7 @@ double _Complex *compute_state_vector(char *filename, int *num_q) {
     }
     const int n = qsim_circuit_num_qubits(c);
     rc = qsim_create(&s, n, env_int("QSIM_DEVICE", 0));
+    if (rc == QSIM_OK) rc = qsim_set_option(s, QSIM_OPT_PINGPONG, 0); /* one circuit, one run: a second buffer costs more to allocate than it saves (main.c) */
     if (rc == QSIM_OK) rc = qsim_apply_env_options(s);
     if (rc == QSIM_OK) rc = qsim_run_circuit(s, c, 0, -1);
     if (rc == QSIM_OK) rc = qsim_sync(s);

@@ -99,6 +99,45 @@ class ShardPlan:
         """Queues this rank's ops of a local step on a Simulator, natively."""
         self.handle.apply_local(step, self.rank, sim)
 
+    def local_sweeps(self, rank: Optional[int] = None) -> dict:
+        """Host only: what rank `rank`'s engine will schedule for its local steps — passes, and the bytes they move in units
+        of one full sweep (read + write) of the shard, the first passes of a sparse phase counted by the fraction of the
+        shard they visit — and what it sends: per exchange the blocks that really travel (the first exchange of a run has
+        shards that hold nothing).  The ingredients of bench.py's exchange_model."""
+        from .simulator import Circuit
+        rank = self.rank if rank is None else rank
+        m, h = self.m, self.handle
+        support, empty = 0, rank != 0
+        out = {"passes": 0, "sweeps": 0.0, "exchanges": [], "steps": []}
+        for i in range(h.num_steps):
+            st = h.step(i)
+            if st[0] == "exchange":
+                ro = h.exchange_roles(i, rank)
+                k = len(st[1])
+                out["exchanges"].append({"qubits": k, "blocks_sent": bin(ro["send"]).count("1"), "blocks_received": bin(ro["recv"]).count("1"),
+                                         "block_bytes": (16 << m) >> k})
+                empty, support = bool(ro["empty_after"]), ro["new_support"]
+                out["steps"].append("exchange")
+                continue
+            if empty:
+                out["steps"].append("holds nothing")
+                continue
+            c = Circuit.empty(m)
+            for op in h.local_ops(i, rank):
+                if op[0] == "cx":
+                    c.append_cx(op[1], op[2])
+                elif op[0] == "u1":
+                    c.append_1q(op[2], op[1])
+                else:
+                    c.append_1q([[op[1], 0], [0, op[1]]], 0)
+            pl = c.plan(initial_support=support)
+            sweeps = pl["algorithmic_bytes"] / (32.0 * (1 << m))
+            out["passes"] += pl["launches"]
+            out["sweeps"] += sweeps
+            out["steps"].append({"passes": pl["launches"], "sweeps": sweeps})
+            support = (1 << m) - 1
+        return out
+
 
 _X = np.array([[0, 1], [1, 0]], dtype=np.complex128)
 
@@ -369,6 +408,18 @@ class ShardedSimulator:
             t = t.cuda()
         self.dist.all_reduce(t)
         return float(t.item())
+
+    def gather_logical(self) -> np.ndarray:
+        """Collective: every rank contributes its shard and gets the whole state in LOGICAL index order (small registers:
+        the self-check of bench.py --gpus N, tests)."""
+        import torch
+        mine = torch.from_numpy(np.ascontiguousarray(self.shard.read_all()).view(np.float64).copy())
+        if self.dist.get_backend() == "nccl":
+            mine = mine.cuda()
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        phys = torch.cat(parts).cpu().numpy().view(np.complex128)
+        return logical_from_physical(phys, self.plan.final_pos)
 
     def amplitude(self, logical_index: int) -> complex:
         """One amplitude by LOGICAL basis index (collective)."""

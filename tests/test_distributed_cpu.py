@@ -137,6 +137,55 @@ def test_gloo_ranks_equal_oracle(oracle, tmp_path, world):
             assert int(g) == w or (abs(int(g) - w) == 1 and min(abs(cumul[w] - r), abs(cumul[int(g)] - r)) < 1e-13)
 
 
+class _BrokenShard(CpuShard):
+    """A shard whose re-layout is wrong (the blocks of an exchange come out in the wrong order)."""
+
+    def pack(self, Lsel):
+        super().pack(Lsel)
+        k = len(Lsel)
+        sc = self.scratch.view(1 << k, -1, 2)
+        sc.copy_(sc.flip(0).clone())
+
+
+def _selfcheck_worker(rank, world, port, broken, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    try:
+        rec = bench.run_selfcheck(dist, 0, shard_factory=_BrokenShard if broken else CpuShard, require_native=False, qubits=13, depth=250)
+        q.put((rank, "ok", rec))
+    except SystemExit as e:
+        q.put((rank, "exit", e.code))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("broken", [False, True])
+def test_bench_selfcheck_on_two_gloo_ranks(broken):
+    """bench.py --gpus N checks a small sharded circuit against the oracle on the same ranks before it times anything
+    (run_selfcheck): here through two gloo ranks with CPU shards — once intact (passes, reports its error), once with a
+    shard whose exchange layout is wrong: every rank stops with exit code 3 and no number would be printed."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_selfcheck_worker, args=(r, world, port, broken, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if broken:
+        assert [r[1:] for r in results] == [("exit", 3), ("exit", 3)]
+    else:
+        assert all(r[1] == "ok" and r[2]["passed"] for r in results)
+        rec = results[0][2]
+        assert rec["max_abs_err"] < 1e-12 and rec["exchanges"] >= 1 and rec["qubits"] == 13
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("n,depth,seed,vocab", [(8, 300, 11, "all"), (12, 600, 12, "all"), (16, 800, 13, "clifford_t"),
                                                 (30, 1000, 20240147, "all")])

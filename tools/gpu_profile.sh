@@ -19,9 +19,9 @@ for l in sys.stdin:
 "
 # kernel trace + stats of the same bench command
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_trace -o bench -- python3 $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-full-sweeps --sizes= --wisdom $OUT/wisdom.txt > $OUT/rocprof_trace.log 2>&1 || echo "rocprof trace failed"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_trace -o bench -- python3 $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-full-sweeps --no-precision32 --no-one-shot --sizes= --wisdom $OUT/wisdom.txt > $OUT/rocprof_trace.log 2>&1 || echo "rocprof trace failed"
 # PMC: separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass); short run to keep the CSV small
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/rocprof_fetch -o bench -- python3 $OLDPWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-full-sweeps --sizes= --wisdom $OUT/wisdom.txt > $OUT/rocprof_fetch.log 2>&1 || echo "rocprof fetch failed"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/rocprof_write -o bench -- python3 $OLDPWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-full-sweeps --sizes= --wisdom $OUT/wisdom.txt > $OUT/rocprof_write.log 2>&1 || echo "rocprof write failed"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/rocprof_fetch -o bench -- python3 $OLDPWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-full-sweeps --no-precision32 --no-one-shot --sizes= --wisdom $OUT/wisdom.txt > $OUT/rocprof_fetch.log 2>&1 || echo "rocprof fetch failed"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/rocprof_write -o bench -- python3 $OLDPWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-full-sweeps --no-precision32 --no-one-shot --sizes= --wisdom $OUT/wisdom.txt > $OUT/rocprof_write.log 2>&1 || echo "rocprof write failed"
 cd $OLDPWD
 find $OUT -name "*.csv" | head -20

@@ -227,6 +227,39 @@ def test_full_size_two_paths_agree(n, vocab):
     assert np.max(np.abs(fused - plain)) < TOL
 
 
+@pytest.mark.parametrize("n", [32, 33])
+def test_largest_registers_two_paths_agree(n):
+    """The two largest north_star sizes, amplitude by amplitude on sampled windows (until now only norms):
+    n = 32 runs its tile passes out of place between two 64 GiB buffers; n = 33 (128 GiB) does the same where the card has
+    room for 2 x 128 GiB next to everything else (it does on the 288 GiB boxes of this pool) and in place otherwise — either
+    way the same amplitudes.  250 gate statements of the `all` vocabulary through fuse 3 (scheduler, merged
+    blocks, k_tile) and through fuse 0 (one launch per statement, kernels that are oracle-checked on every target bit);
+    ~20 000 sampled amplitudes within 1e-10, both norms 1."""
+    depth = 250
+    gates = circuits.random_gates(n, depth, 20240117 + n, "all")
+    c = Circuit.from_gates(n, gates)
+    with Simulator(n, fuse=3) as sim:
+        sim.run(c)
+        assert abs(sim.norm2() - 1.0) < 1e-10
+        fused = _sample_windows(sim, n, 11)
+        st = sim.stats()
+        assert st["launches"] < 20 and st["kernels"]["tile"]["launches"] >= 3
+        import torch
+        free_b, total_b = torch.cuda.mem_get_info()
+        two_buffers = (total_b - free_b) > 1.5 * (16 << n)
+        assert two_buffers or n == 33
+        sim.reset()
+        sim.set_option(_lib.OPT_FUSE, 0)
+        sim.reset_stats()
+        sim.run(c)
+        assert abs(sim.norm2() - 1.0) < 1e-10
+        plain = _sample_windows(sim, n, 11)
+        st = sim.stats()
+        assert st["launches"] >= depth - 5 and st["kernels"]["tile"]["launches"] == 0
+    assert np.max(np.abs(fused)) > 1e-7
+    assert np.max(np.abs(fused - plain)) < TOL
+
+
 def _inverse(gates):
     inv = []
     for g in reversed(gates):

@@ -435,9 +435,12 @@ class Bench:
                                "bytes_sent_per_rank_per_step": xb, "seconds_per_step": xs,
                                "xgmi_gbps_per_rank": (xb / xs / 1e9) if xs > 0 else None,
                                "backend": getattr(sim, "exchange_backend", None),
+                               "relayouts_fused_separate": (list(sim.shard.comm.pack_counts()) if getattr(sim.shard, "comm", None) is not None else None),
                                "predicted": getattr(sim, "exchange_prediction", None),
-                               "note": "seconds: pack + send/recv of rank 0 (rccl-native: HIP events on the engine's stream; "
-                                       "torch.distributed: host clock incl. the stream hand-offs)"}
+                               "note": "seconds: rank 0's transfers (rccl-native: HIP events on the engine's stream around the ncclGroup; the "
+                                       "re-layout rides on the last tile pass before the exchange and is not in it, a separate pack kernel is; "
+                                       "torch.distributed fallback: host clock incl. pack and the stream hand-offs); bytes: blocks that really "
+                                       "travelled (ranks that hold nothing yet send nothing)"}
         sim.close()
         del sim
         return res

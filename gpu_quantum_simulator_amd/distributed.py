@@ -255,10 +255,11 @@ class ShardedSimulator:
         _bind(self.shard, self.plan)
         self._xsec = 0.0
         self._xbytes = 0
-        bytes_per_rank, seconds = self.plan.predict()
-        self.exchange_prediction = {"model": "per exchange: pack pass (2 x shard bytes at 5 TB/s) + 2^-k of the shard per link "
-                                             "(50 GB/s per link and direction, 2^k - 1 links at once)",
-                                    "bytes_sent_per_rank_per_step": bytes_per_rank, "seconds_per_step": seconds}
+        sent = [x["blocks_sent"] * x["block_bytes"] for x in self.plan.local_sweeps()["exchanges"]]
+        per_link = [x["block_bytes"] for x in self.plan.local_sweeps()["exchanges"] if x["blocks_sent"] or x["blocks_received"]]
+        self.exchange_prediction = {"model": "per exchange: 2^-k of the shard per link, 2^k - 1 links at once, 50 GB/s per link and direction; blocks "
+                                             "of ranks that hold nothing yet stay home; the re-layout rides on the last tile pass before the exchange",
+                                    "bytes_sent_by_this_rank_per_step": float(sum(sent)), "seconds_per_step": sum(b / 50e9 for b in per_link)}
         self.exchange_backend = "torch.distributed"
         import os
         # QSIM_EXCHANGE=torch keeps the round-1 form (pack, then torch.distributed send/recv on torch's stream): an

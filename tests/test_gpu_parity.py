@@ -235,8 +235,8 @@ def test_largest_registers_two_paths_agree(n):
     way the same amplitudes.  250 gate statements of the `all` vocabulary through fuse 3 (scheduler, merged
     blocks, k_tile) and through fuse 0 (one launch per statement, kernels that are oracle-checked on every target bit);
     ~20 000 sampled amplitudes within 1e-10, both norms 1."""
-    depth = 250
-    gates = circuits.random_gates(n, depth, 20240117 + n, "all")
+    gates = [("h", q) for q in range(n)] + circuits.random_gates(n, 250, 20240117 + n, "all")  # the layer of h: every sampled window is populated
+    depth = len(gates)
     c = Circuit.from_gates(n, gates)
     with Simulator(n, fuse=3) as sim:
         sim.run(c)
@@ -256,7 +256,7 @@ def test_largest_registers_two_paths_agree(n):
         plain = _sample_windows(sim, n, 11)
         st = sim.stats()
         assert st["launches"] >= depth - 5 and st["kernels"]["tile"]["launches"] == 0
-    assert np.max(np.abs(fused)) > 1e-7
+    assert np.count_nonzero(np.abs(fused) > 1e-7) > fused.size // 16  # (a second h on a qubit empties half of the windows again)
     assert np.max(np.abs(fused - plain)) < TOL
 
 

@@ -858,7 +858,7 @@ static bool plan_matches(const PlanIdentity &have, const PlanIdentity &want, con
 // that were never planned use the default.
 // The table is found by key alone: a colliding circuit would be scheduled with another circuit's variant — a valid schedule
 // either way (every variant is; the results never depend on it).  Bounded: beyond kMaxSchedHints circuits it starts afresh.
-struct SchedHint { int commute; double cheap_margin; int lookahead; };
+struct SchedHint { int commute; double cheap_margin; int lookahead; int cap; /* clusters per pass; 0: the configuration's own */ };
 static std::mutex g_hints_mu;
 static std::map<uint64_t, SchedHint> g_sched_hints;
 constexpr size_t kMaxSchedHints = 4096;
@@ -869,6 +869,7 @@ static void apply_sched_hint(uint64_t key, SchedConfig &cfg) {
     cfg.commute = it->second.commute;
     cfg.cheap_margin = it->second.cheap_margin;
     cfg.lookahead = it->second.lookahead;
+    if (it->second.cap > 0) { cfg.tile_max_ops = it->second.cap; cfg.tail_max_ops = std::max(cfg.tail_max_ops, it->second.cap); }
 }
 static bool have_sched_hints() {
     std::lock_guard<std::mutex> lock(g_hints_mu);
@@ -1483,9 +1484,42 @@ static void feed(Scheduler &sched, const qsim_circuit *c) {
     }
 }
 
-// Schedules the circuit under a handful of scheduler settings, remembers the one whose passes move the fewest bytes under
-// the key qsim_flush will compute for the same gates on a state with this support, and hands its passes back.
-static void choose_schedule(qsim_state *s, const qsim_circuit *c, const SchedConfig &scfg, std::vector<Pass> *out) {
+// What a pass costs, in bytes moved at the rate of a pass that is bound by its memory traffic.  A tile pass is: up to four
+// merged blocks hide behind the HBM time of the sweep, every further one adds 11 % of it (fp64; fp32 moves half the bytes
+// per amplitude under the same blocks: 20 % from the fourth on).  Fitted on 599 passes of six circuits under six cluster
+// caps at n = 30 (tools/pass_model_data.py, profiles/r03/pass_model_n30.csv): ms = visited x (6.93 + 0.77 x max(0, blocks - 4)),
+// rms error 0.41 ms.  The planning step ranks schedules by the sum of this — fewer sweeps are worth more than leaner ones,
+// but not at any number of blocks.
+static double pass_cost(const Pass &p, bool f32) {
+    if (p.kclass != QSIM_K_TILE) return p.bytes;
+    const int nb = (int)p.blocks.size() - p.geom.n_scale;
+    const double extra = f32 ? 0.20 * std::max(0, nb - 3) : 0.111 * std::max(0, nb - 4);
+    return p.bytes * p.visited * (1.0 + extra);
+}
+
+// Schedules the circuit under a few dozen scheduler settings, remembers the one whose passes are predicted to take the least
+// time (pass_cost) under the key qsim_flush will compute for the same gates on a state with this support, and hands its
+// passes back.
+struct RankedVariant { SchedHint hint; double cost; bool is_default; };
+// circuits whose schedule was chosen by MEASUREMENT (qsim_tune_circuit): the choice stands until the table is cleared — timing
+// the same candidates again could flip between near-equal schedules and invalidate the geometries measured for the winner
+static std::map<uint64_t, RankedVariant> g_sched_measured; // guarded by g_hints_mu
+static void set_sched_hint(uint64_t key, const SchedHint &now, bool is_default, const SchedConfig &scfg) {
+    std::lock_guard<std::mutex> lock(g_hints_mu);
+    const auto it = g_sched_hints.find(key);
+    const SchedHint dflt{scfg.commute, scfg.cheap_margin, scfg.lookahead, 0};
+    const SchedHint before = it == g_sched_hints.end() ? dflt : it->second;
+    if (is_default) g_sched_hints.erase(key);
+    else {
+        if (g_sched_hints.size() >= kMaxSchedHints && it == g_sched_hints.end()) g_sched_hints.clear();
+        g_sched_hints[key] = now;
+    }
+    if (before.commute != now.commute || before.cheap_margin != now.cheap_margin || before.lookahead != now.lookahead || before.cap != now.cap)
+        g_wisdom_epoch++; // cached plans of this circuit were scheduled another way
+}
+
+static void choose_schedule(qsim_state *s, const qsim_circuit *c, const SchedConfig &scfg, std::vector<Pass> *out,
+                            std::vector<RankedVariant> *ranked = nullptr, uint64_t *key_out = nullptr) {
     std::vector<Pass> passes;
     if (s->fuse < 3) {
         Scheduler sv(scfg);
@@ -1503,39 +1537,56 @@ static void choose_schedule(qsim_state *s, const qsim_circuit *c, const SchedCon
         for (int k = 0; U && k < (g.kind == QSIM_GATE_U1 ? 4 : 16); k++) o.m[k] = cd(U[2 * k], U[2 * k + 1]);
     }
     const uint64_t key = gates_key(s, plan_identity(s, q.size(), scfg.initial_support), q.data(), q.size());
-    // the variants: clusters may / may not overtake (commute), how eagerly passes inside the support are kept (cheap_margin),
-    // one more pass of lookahead where the local search is on; the default comes first and wins ties
+    // the variants: how many clusters a pass may take (where the engine sets a cap of its own: states of 4 GiB and more),
+    // clusters may / may not overtake (commute), how eagerly passes inside the support are kept (cheap_margin), one more
+    // pass of lookahead where the local search is on; the default comes first and wins ties
     std::vector<SchedHint> variants;
-    for (int com = 1; com >= 0; com--)
-        for (double mar : {scfg.cheap_margin, 2.0 * scfg.cheap_margin})
-            for (int la = scfg.lookahead; la <= scfg.lookahead + (scfg.lookahead >= 1 ? 1 : 0); la++) variants.push_back({com, mar, la});
+    std::vector<int> caps{0};
+    if (scfg.tail_max_ops > scfg.tile_max_ops) // the engine's own cap is in force (engine_sched_config), not a caller's
+        for (int cap : {24, 28, 32, 40})
+            if (cap != scfg.tile_max_ops) caps.push_back(cap);
+    for (int cap : caps)
+        for (int com = 1; com >= 0; com--)
+            for (double mar : {scfg.cheap_margin, 2.0 * scfg.cheap_margin})
+                for (int la = scfg.lookahead; la <= scfg.lookahead + (scfg.lookahead >= 1 ? 1 : 0); la++) variants.push_back({com, mar, la, cap});
     double best_cost = 0;
     size_t best = 0;
     for (size_t vi = 0; vi < variants.size(); vi++) {
         SchedConfig v = scfg;
         v.commute = variants[vi].commute; v.cheap_margin = variants[vi].cheap_margin; v.lookahead = variants[vi].lookahead;
+        if (variants[vi].cap > 0) { v.tile_max_ops = variants[vi].cap; v.tail_max_ops = std::max(v.tail_max_ops, variants[vi].cap); }
         Scheduler sv(v);
         feed(sv, c);
         std::vector<Pass> pv;
         sv.finish(pv);
         double cost = 0;
-        for (const Pass &p : pv) cost += p.bytes * p.visited;
+        for (const Pass &p : pv) cost += pass_cost(p, s->f32);
+        if (ranked) ranked->push_back({variants[vi], cost, vi == 0});
         if (vi == 0 || cost < best_cost * 0.995) { best_cost = cost; best = vi; passes = std::move(pv); }
     }
+    if (key_out) *key_out = key;
     {
-        std::lock_guard<std::mutex> lock(g_hints_mu);
-        const auto it = g_sched_hints.find(key);
-        const SchedHint dflt{scfg.commute, scfg.cheap_margin, scfg.lookahead};
-        const SchedHint before = it == g_sched_hints.end() ? dflt : it->second;
-        const SchedHint now = variants[best];
-        if (best == 0) g_sched_hints.erase(key);
-        else {
-            if (g_sched_hints.size() >= kMaxSchedHints && it == g_sched_hints.end()) g_sched_hints.clear();
-            g_sched_hints[key] = now;
+        bool measured = false;
+        RankedVariant kept{};
+        {
+            std::lock_guard<std::mutex> lock(g_hints_mu);
+            auto it = g_sched_measured.find(key);
+            if (it != g_sched_measured.end()) { measured = true; kept = it->second; }
         }
-        if (before.commute != now.commute || before.cheap_margin != now.cheap_margin || before.lookahead != now.lookahead)
-            g_wisdom_epoch++; // cached plans of this circuit were scheduled another way
+        if (measured) { // keep the measured choice; hand back ITS passes
+            SchedConfig v = scfg;
+            v.commute = kept.hint.commute; v.cheap_margin = kept.hint.cheap_margin; v.lookahead = kept.hint.lookahead;
+            if (kept.hint.cap > 0) { v.tile_max_ops = kept.hint.cap; v.tail_max_ops = std::max(v.tail_max_ops, kept.hint.cap); }
+            Scheduler sv(v);
+            feed(sv, c);
+            passes.clear();
+            sv.finish(passes);
+            if (ranked) ranked->clear(); // nothing left to try
+            if (out) *out = std::move(passes);
+            return;
+        }
     }
+    set_sched_hint(key, variants[best], best == 0, scfg);
     if (out) *out = std::move(passes);
 }
 
@@ -1599,10 +1650,72 @@ extern "C" int qsim_tune_circuit_support(qsim_state *s, const qsim_circuit *c, i
     }
     SchedConfig scfg = sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32,
                                     support); // 0: the run that follows starts from the reset this call ends with
-    // Which way to schedule THIS circuit (SchedConfig::commute) is decided first; its passes are the ones measured below.
+    // Which way to schedule THIS circuit is decided first; its passes are the ones measured below.  The pass-time model ranks
+    // the scheduler settings (choose_schedule); with timing allowed (max_candidates > 1) the four schedules it likes best
+    // are then RUN once each on the state — the model is good to ~0.4 ms per pass, i.e. it cannot tell schedules apart
+    // that differ by less than ~2 % — and the fastest is kept.
     std::vector<Pass> passes;
-    choose_schedule(s, c, scfg, &passes);
+    std::vector<RankedVariant> ranked;
+    uint64_t sched_key = 0;
+    choose_schedule(s, c, scfg, &passes, &ranked, &sched_key);
     qsim_tune_report r{};
+    if (max_candidates > 1 && s->fuse >= 3 && ranked.size() > 1) {
+        std::stable_sort(ranked.begin(), ranked.end(), [](const RankedVariant &a, const RankedVariant &b) { return a.cost < b.cost; });
+        std::vector<RankedVariant> tries;
+        for (const RankedVariant &v : ranked) { // distinct predicted costs = (almost surely) distinct schedules
+            bool dup = false;
+            for (const RankedVariant &t : tries) dup = dup || t.cost == v.cost;
+            if (!dup) tries.push_back(v);
+            if (tries.size() == 4) break;
+        }
+        hipEvent_t t0 = nullptr, t1 = nullptr;
+        HIP_TRY(hipEventCreate(&t0));
+        HIP_TRY(hipEventCreate(&t1));
+        const int saved_profile = s->profile;
+        s->profile = 0;
+        const uint64_t nmask = s->n >= 64 ? ~0ULL : ((1ULL << s->n) - 1ULL);
+        float best_ms = 0.f;
+        size_t best_i = 0;
+        for (size_t i = 0; i < tries.size() && rc == QSIM_OK; i++) {
+            set_sched_hint(sched_key, tries[i].hint, tries[i].is_default, scfg);
+            float ms = 0.f;
+            for (int rep2 = 0; rep2 < 2 && rc == QSIM_OK; rep2++) { // the second run replays the cached plan: no host work in the way
+                if (support == 0) rc = qsim_reset(s);
+                else if (support != ~0ULL) rc = qsim_set_support(s, support & nmask);
+                else { s->zero_ket_pending = false; s->partial = false; } // a dense state: whatever the buffer holds
+                if (rc) break;
+                (void)hipEventRecord(t0, s->stream);
+                rc = qsim_run_circuit(s, c, 0, -1);
+                if (rc == QSIM_OK) rc = qsim_flush(s);
+                (void)hipEventRecord(t1, s->stream);
+                if (rc == QSIM_OK && hipEventSynchronize(t1) != hipSuccess) rc = fail(QSIM_ERR_DEVICE, "planning: event sync failed");
+                if (rc == QSIM_OK && hipEventElapsedTime(&ms, t0, t1) != hipSuccess) rc = fail(QSIM_ERR_DEVICE, "planning: event time failed");
+            }
+            if (i == 0 || ms < best_ms) { best_ms = ms; best_i = i; }
+        }
+        s->profile = saved_profile;
+        s->stats.gates -= std::min<uint64_t>(s->stats.gates, (uint64_t)c->count * 2 * tries.size()); // planning runs are not gate statements of the caller
+        (void)hipEventDestroy(t0);
+        (void)hipEventDestroy(t1);
+        if (rc) return rc;
+        set_sched_hint(sched_key, tries[best_i].hint, tries[best_i].is_default, scfg);
+        {
+            std::lock_guard<std::mutex> lock(g_hints_mu);
+            if (g_sched_measured.size() >= kMaxSchedHints) g_sched_measured.clear();
+            g_sched_measured[sched_key] = tries[best_i];
+        }
+        { // the passes of the schedule that won: the ones whose tile-bit orders are measured below
+            SchedConfig v = scfg;
+            v.commute = tries[best_i].hint.commute; v.cheap_margin = tries[best_i].hint.cheap_margin; v.lookahead = tries[best_i].hint.lookahead;
+            if (tries[best_i].hint.cap > 0) { v.tile_max_ops = tries[best_i].hint.cap; v.tail_max_ops = std::max(v.tail_max_ops, tries[best_i].hint.cap); }
+            Scheduler sv(v);
+            feed(sv, c);
+            passes.clear();
+            sv.finish(passes);
+        }
+        rc = qsim_sync(s);
+        if (rc) return rc;
+    }
     std::vector<const Pass *> todo;
     for (const Pass &p : passes) {
         if (p.kclass != QSIM_K_TILE) continue;
@@ -1743,6 +1856,7 @@ extern "C" void qsim_tune_table_clear(void) {
     {
         std::lock_guard<std::mutex> lock(g_hints_mu);
         g_sched_hints.clear();
+        g_sched_measured.clear();
     }
     std::lock_guard<std::mutex> lock(g_wisdom_mu);
     g_wisdom.clear();

@@ -154,7 +154,10 @@ SchedConfig engine_sched_config(int n, int fuse, int tile_bits, int tile_low_bit
     if (fuse >= 3 && size_class >= 28) {
         c.local_iters = 3;
         c.lookahead = 1;
-        if (tile_max_ops == 32) { c.tile_max_ops = 24; c.tail_max_ops = 32; } // 32 = the option's default, i.e. not chosen by the caller
+        // Round 3 re-measured the cap with the cheaper block phase of round 2 (tools/cap_sweep.py, five seeded circuits at n = 30, no
+        // planning step): 24 clusters 404 ms in total, 28 373 ms, 32 385 ms, 40 374 ms — and no single value is best for every
+        // circuit (per-circuit minima add up to 363 ms), so 28 is the default and the planning step tries 24 / 32 / 40 as well.
+        if (tile_max_ops == 32) { c.tile_max_ops = 28; c.tail_max_ops = 32; } // 32 = the option's default, i.e. not chosen by the caller
     }
     return c;
 }

@@ -1,0 +1,27 @@
+"""(visited, blocks, ms) of every tile pass over several circuits and scheduler variants: data for the pass-time model of the planning step."""
+import os, sys
+from ctypes import byref, c_double
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from gpu_quantum_simulator_amd import Circuit, Simulator, circuits, _lib
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+seeds = [20240117 + n, 1, 2, 3, 4, 5]
+circs = [Circuit.from_gates(n, circuits.random_gates(n, 1000, s, "all")) for s in seeds]
+variants = [{}, {"QSIM_SCHED_CAP": "28"}, {"QSIM_SCHED_CAP": "32"}, {"QSIM_SCHED_CAP": "40"}, {"QSIM_SCHED_CAP": "48"}, {"QSIM_SCHED_CAP": "16"}]
+lib = _lib.load()
+print("visited,blocks,ms")
+with Simulator(n, profile=True) as sim:
+    for env in variants:
+        for k in list(os.environ):
+            if k.startswith("QSIM_SCHED_"):
+                del os.environ[k]
+        os.environ.update(env)
+        for c in circs:
+            sim.reset(); sim.run(c); sim.sync()
+            sim.reset_stats()
+            sim.reset(); sim.run(c); sim.sync()
+            for i, (k, o, hm, ms) in enumerate(sim.launch_log()):
+                if k != "tile":
+                    continue
+                v = c_double()
+                lib.qsim_launch_log_visited(sim._h, i, byref(v))
+                print(f"{v.value:.6g},{o},{ms:.4f}", flush=True)

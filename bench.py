@@ -80,7 +80,7 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-KERNEL_SYMBOL = {"tile": "k_tile<12, 512, false>", "gate1": "k_gate1_hi<4, false>",
+KERNEL_SYMBOL = {"tile": "k_tile<12, 512, false, false>", "gate1": "k_gate1_hi<4, false>",
                  "gate1_lo": "k_gate1_lo<4, false>", "gate2": "k_gate2_hh<2, false>"}  # inside namespace qsim::f64
 
 
@@ -481,7 +481,7 @@ def main():
     default_workload = (args.precision == 64 and args.probe is None and n == 30 and args.depth == 1000 and args.fuse == 3 and args.gpus == 1
                         and not opts and args.vocabulary == "all" and b.dist is None)
     head = b.measure(n, args.depth, args.vocabulary, seed, args.steps, args.warmup, args.fuse, opts,
-                     probe_q=args.probe, with_1q_probe=True, cold=default_workload and not args.wisdom and not args.no_one_shot)
+                     probe_q=args.probe, with_1q_probe=True, cold=default_workload and not args.no_one_shot and not (args.wisdom and os.path.exists(args.wisdom)))
 
     # other register sizes, same generator and defaults (north_star: n = 24/28/30/32)
     sizes = []

@@ -1807,6 +1807,12 @@ extern "C" int qsim_tune_table_save(const char *path) {
     if (!path) return fail(QSIM_ERR_ARG, "NULL path");
     FILE *f = fopen(path, "w");
     if (!f) return fail(QSIM_ERR_OPEN, "cannot write %s", path);
+    {   // measured schedule choices: "sched <key> <commute> <cheap_margin> <lookahead> <cap> <is_default>"
+        std::lock_guard<std::mutex> lock(g_hints_mu);
+        for (const auto &kv : g_sched_measured)
+            fprintf(f, "sched %llx %d %.17g %d %d %d\n", (unsigned long long)kv.first, kv.second.hint.commute, kv.second.hint.cheap_margin,
+                    kv.second.hint.lookahead, kv.second.hint.cap, kv.second.is_default ? 1 : 0);
+    }
     std::lock_guard<std::mutex> lock(g_wisdom_mu);
     for (const auto &kv : g_wisdom) {
         const int nh = __builtin_popcountll(kv.first.high_mask);
@@ -1826,6 +1832,21 @@ extern "C" long qsim_tune_table_load(const char *path) {
     long loaded = 0;
     char line[512];
     while (fgets(line, sizeof line, f)) {
+        if (strncmp(line, "sched ", 6) == 0) {
+            unsigned long long key = 0;
+            RankedVariant rv{};
+            int isd = 0;
+            if (sscanf(line + 6, "%llx %d %lf %d %d %d", &key, &rv.hint.commute, &rv.hint.cheap_margin, &rv.hint.lookahead, &rv.hint.cap, &isd) == 6 &&
+                rv.hint.cheap_margin > 0 && rv.hint.lookahead >= 0 && rv.hint.lookahead <= 8 && rv.hint.cap >= 0 && rv.hint.cap <= 512) {
+                rv.is_default = isd != 0;
+                std::lock_guard<std::mutex> lock(g_hints_mu);
+                g_sched_measured[key] = rv;
+                if (rv.is_default) g_sched_hints.erase(key); else g_sched_hints[key] = rv.hint;
+                g_wisdom_epoch++;
+                loaded++;
+            }
+            continue;
+        }
         GeomKey k{};
         GeomOrder o{};
         unsigned long long hm = 0;

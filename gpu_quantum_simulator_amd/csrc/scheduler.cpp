@@ -115,6 +115,8 @@ SchedEnv read_sched_env() {
     if (const char *v = getenv("QSIM_SCHED_CHEAP")) { e.cheap_margin = atof(v); e.set |= 1u << bit; }
     bit++;
     if (getenv("QSIM_SCHED_NOCOMMUTE")) e.set |= 1u << bit;
+    bit++;
+    geti("QSIM_SCHED_SEED", e.seed);
     return e;
 }
 
@@ -131,6 +133,7 @@ void apply_sched_env(const SchedEnv &e, SchedConfig &cfg) {
     if (on()) { cfg.tile_max_ops = e.cap; cfg.tail_max_ops = 0; }
     if (on()) cfg.cheap_margin = e.cheap_margin;
     if (on()) cfg.commute = 0;
+    if (on()) cfg.seed = (uint64_t)e.seed;
 }
 
 Scheduler::Scheduler(const SchedConfig &cfg) : cfg_(cfg), open_(cfg.n > 0 ? cfg.n : 0, -1) { apply_sched_env(read_sched_env(), cfg_); }
@@ -619,6 +622,12 @@ void Scheduler::build_passes(const PassSink &sink) {
         must[i] = cfg_.selectors ? (qm[i] & ~closed_[i].selector_mask()) : qm[i];
     }
     std::vector<char> done(m, 0), trial;
+    uint64_t rng = cfg_.seed * 0x9E3779B97F4A7C15ULL + 0xD1B54A32D192ED03ULL; // xorshift64*: SchedConfig::seed
+    auto coin = [&]() {
+        if (!cfg_.seed) return false;
+        rng ^= rng >> 12; rng ^= rng << 25; rng ^= rng >> 27;
+        return ((rng * 0x2545F4914F6CDD1DULL) >> 63) != 0;
+    };
     int cap = cfg_.tile_max_ops; // clusters per pass; lifted to tail_max_ops when that lets a pass finish the circuit
     size_t first = 0;
     std::vector<FusedOp> group;
@@ -812,7 +821,7 @@ void Scheduler::build_passes(const PassSink &sink) {
                     trial = work;
                     trial[(size_t)cands[t].idx] = 1;
                     const int score = rollout(trial, first, end, hset | (must[(size_t)cands[t].idx] & ~lowmask), have + 1);
-                    if (score > best_score) { best_score = score; pick = cands[t]; }
+                    if (score > best_score || (score == best_score && coin())) { best_score = score; pick = cands[t]; }
                 }
             }
             hset |= must[(size_t)pick.idx] & ~lowmask;
@@ -838,7 +847,7 @@ void Scheduler::build_passes(const PassSink &sink) {
                         if (hset >> b & 1ULL) continue;
                         const uint64_t S2 = (hset & ~qi) | (1ULL << b);
                         const int v = eval_ahead(first, end, S2, nullptr);
-                        if (v > best) { best = v; bestS = S2; }
+                        if (v > best || (v == best && bestS != hset && coin())) { best = v; bestS = S2; }
                     }
                 }
                 if (bestS == hset) break;

@@ -139,6 +139,8 @@ struct SchedConfig {
     // seeded 1000-gate circuits at n = 30: 892 -> 835 ms in total) but the greedy packing does not use it well on every
     // circuit, so the planning step (qsim_tune_circuit) schedules both ways and keeps the cheaper one for that circuit.
     int commute = 1;
+    uint64_t seed = 0; // != 0: ties between equally good candidates (which cluster to admit next, which qubit to swap) are broken pseudo-randomly
+                       // instead of in index order — another valid schedule of the same circuit per seed, for the planning step to choose among
     int track = 0; // 1: every pass lists the gates it absorbed (Pass::src) — the shard planner asks which gates a segment's last pass holds
 };
 
@@ -153,11 +155,11 @@ SchedConfig engine_sched_config(int n, int fuse, int tile_bits, int tile_low_bit
 // another).  `set` has one bit per variable that is present.
 struct SchedEnv {
     uint32_t set = 0;
-    int lookahead = 0, rollout = 0, window = 0, local_iters = 0, objective = 0, merge = 0, merge_qubits = 0, cap = 0;
+    int lookahead = 0, rollout = 0, window = 0, local_iters = 0, objective = 0, merge = 0, merge_qubits = 0, cap = 0, seed = 0;
     double cheap_margin = 0;
     bool operator==(const SchedEnv &o) const {
         return set == o.set && lookahead == o.lookahead && rollout == o.rollout && window == o.window && local_iters == o.local_iters &&
-               objective == o.objective && merge == o.merge && merge_qubits == o.merge_qubits && cap == o.cap && cheap_margin == o.cheap_margin;
+               objective == o.objective && merge == o.merge && merge_qubits == o.merge_qubits && cap == o.cap && seed == o.seed && cheap_margin == o.cheap_margin;
     }
 };
 SchedEnv read_sched_env();                      // the environment as it is now

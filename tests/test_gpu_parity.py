@@ -1086,8 +1086,9 @@ def test_planning_for_a_dense_start(oracle):
 
 def test_planning_keeps_the_cheaper_of_the_two_schedules(oracle, tmp_path):
     """SchedConfig::commute: clusters that are block-diagonal in every qubit they share may overtake each other.  Both ways
-    are valid schedules; qsim_tune_circuit plans a circuit under a handful of scheduler settings (both orders among them),
-    remembers the one that moves the fewest bytes, and the run after it follows that choice.  Amplitudes equal the oracle's."""
+    are valid schedules; qsim_tune_circuit plans a circuit under a few dozen scheduler settings (both orders among them),
+    remembers the one its pass-time model likes best (bytes moved, plus 11 % of a sweep for every merged block beyond four),
+    and the run after it follows that choice.  Amplitudes equal the oracle's."""
     n = 20
     lib = _lib.load()
     seen = set()
@@ -1115,9 +1116,9 @@ def test_planning_keeps_the_cheaper_of_the_two_schedules(oracle, tmp_path):
             moved = sim.stats()["algorithmic_bytes"]
             best = 0 if costs[0] < 0.995 * costs[1] else 1
             seen.add(best)
-            # the planned run is at least as cheap as the better of the two orders (planning also tries two other settings);
-            # the engine counts the generating first pass as a write only, a few KiB less than the plan's figure
-            assert moved <= costs[best] * (1 + 2e-3), (seed, costs, moved)
+            # the planned run moves no more bytes than the better of the two orders, give or take what the model trades for
+            # leaner passes (a few per cent)
+            assert moved <= costs[best] * 1.03, (seed, costs, moved)
     lib.qsim_tune_table_clear()
     assert seen == {0, 1}  # both outcomes were exercised
 

@@ -51,11 +51,11 @@ def test_geometry_table_file_round_trip(tmp_path):
     lib.qsim_tune_table_clear()
     assert lib.qsim_tune_table_size() == 0
     # measured schedule choices travel in the same file ("sched" lines: circuit key, scheduler setting), malformed ones are skipped
-    src.write_text("sched 1234abcd 0 2 2 32 0\nsched 77 1 1 1 0 1\nsched zz\nsched 5 1 -1 1 0 0\n30 0 12 3 3b00000 6.5600 7.6700 25 20 24 21 23\n")
+    src.write_text("sched 1234abcd 0 2 2 32 0 7\nsched 77 1 1 1 0 1\nsched zz\nsched 5 1 -1 1 0 0\n30 0 12 3 3b00000 6.5600 7.6700 25 20 24 21 23\n")
     assert lib.qsim_tune_table_load(str(src).encode()) == 3 and lib.qsim_tune_table_size() == 1
     assert lib.qsim_tune_table_save(str(out).encode()) == 0
     lines = sorted(out.read_text().splitlines())
-    assert lines == ["30 0 12 3 3b00000 6.5600 7.6700 25 20 24 21 23", "sched 1234abcd 0 2 2 32 0", "sched 77 1 1 1 0 1"]
+    assert lines == ["30 0 12 3 3b00000 6.5600 7.6700 25 20 24 21 23", "sched 1234abcd 0 2 2 32 0 7", "sched 77 1 1 1 0 1 0"]  # ... cap, default?, tie-break seed
     lib.qsim_tune_table_clear()
     assert lib.qsim_tune_table_save(str(out).encode()) == 0 and out.read_text() == ""
 

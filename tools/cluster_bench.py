@@ -4,9 +4,12 @@ import os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from gpu_quantum_simulator_amd import Circuit, Cluster, Simulator, circuits
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+MEASURED = len(sys.argv) > 2 and sys.argv[2] == "measured"  # planning with timing (qsim_tune_circuit / qsim_cluster_plan with candidates) instead of the model alone
 c = Circuit.from_gates(n, circuits.random_gates(n, 1000, 20240117 + n, "all"))
 with Simulator(n) as sim:
     sim.choose_schedule(c)
+    if MEASURED:
+        sim.tune(c, 16, 6000.0)
     def body():
         sim.reset(); sim.run(c); sim.sync()
     body()
@@ -14,7 +17,7 @@ with Simulator(n) as sim:
     print(f"single      : {dt*1e3:8.2f} ms/iter  launches/iter={sim.stats()['launches']//3}", flush=True)
 for P in (2, 4, 8):
     with Cluster(n, P, devices=[0] * P) as cl:
-        cl.plan(c)  # the schedule choice per shard and local step, like sim.choose_schedule above (host work, outside the clock)
+        cl.plan(c, 16 if MEASURED else 1, 12000.0)  # the schedule choice per shard and local step, like the single state above (outside the clock)
         cl.run(c)
         t0 = time.perf_counter(); cl.run(c); cl.run(c); dt = (time.perf_counter() - t0) / 2
         ex, nb = cl.exchange_stats()

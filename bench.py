@@ -406,6 +406,10 @@ class Bench:
             tuning = sim.tune(circuit, args.tune_candidates, args.tune_ms)
             # with a loaded table (--wisdom) that step already ran in the measured orders: nothing "untuned" to report
             tuning["untuned_ms_per_step"] = untuned_ms if tuning["already_known"] == 0 else None
+            if not args.no_full_sweeps:
+                # the comparison run with every pass a full sweep schedules differently (no sparse phase): the same planning for it
+                dense = sim.tune(circuit, args.tune_candidates, args.tune_ms / 2, dense_start=True)
+                tuning["full_sweeps_planning_seconds"] = dense["seconds"]
         for _ in range(warmup):
             run_step()
         self.fence(sim)

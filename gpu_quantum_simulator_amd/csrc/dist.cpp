@@ -63,6 +63,7 @@ struct Plan {
     std::vector<int> final_pos;
     int exchanges = 0;
     int tail_gates = 0; // gate statements handed on across an exchange (small_tail)
+    double local_sweeps = 0; // predicted time of the local steps on their busiest shard, in sweeps of the shard (pass_time_cost)
 };
 
 constexpr long kInf = 1L << 60;
@@ -213,10 +214,11 @@ std::vector<size_t> small_tail(const std::vector<LGate> &run, const std::vector<
 // schedule), so it does not matter whether the engine later takes this very schedule or another variant of it; what matters
 // is that every rank computes the same mask, which it does: same plan, same code.  Tighter than counting the qubits some
 // non-diagonal gate has touched (x q; cx q,t; x q leaves q where it was, and the fused cluster shows it).
-uint64_t scheduled_support(const std::vector<LocalOp> &ops, int m, uint64_t support) {
+// cost_sweeps (optional): += what the step is predicted to take, in sweeps of the shard (pass_time_cost).
+uint64_t scheduled_support(const std::vector<LocalOp> &ops, int m, uint64_t support, double *cost_sweeps = nullptr) {
     const uint64_t all = m >= 64 ? ~0ULL : ((1ULL << m) - 1ULL);
-    if ((support & all) == all || ops.empty()) return support & all;
-    qsim::Scheduler sched(qsim::engine_sched_config(m, 3, 12, 3, 32, 10, false, support & all));
+    if (ops.empty() || (!cost_sweeps && (support & all) == all)) return support & all;
+    qsim::Scheduler sched(qsim::engine_sched_config(m, 3, 12, 3, 32, 10, false, (support & all) == all ? ~0ULL : (support & all)));
     for (const LocalOp &o : ops) {
         if (o.kind == 2) sched.add_cx(o.a, o.b);
         else if (o.kind == 1) sched.add_1q(o.m, o.a);
@@ -224,6 +226,7 @@ uint64_t scheduled_support(const std::vector<LocalOp> &ops, int m, uint64_t supp
     }
     uint64_t sup = support & all;
     sched.finish([&](qsim::Pass &&ps) {
+        if (cost_sweeps) *cost_sweeps += qsim::pass_time_cost(ps, false) / (32.0 * (double)(1ULL << m));
         if (ps.kclass != QSIM_K_TILE) { sup = all; return; } // a single-gate kernel: the engine writes the zeros out first
         sup |= (1ULL << ps.geom.low_bits) - 1ULL;
         for (int j = 0; j < ps.geom.n_high; j++) sup |= 1ULL << ps.geom.high[j];
@@ -238,7 +241,7 @@ int tail_limit() {
     return 24;
 }
 
-bool build_plan_policy(int n, int p, const std::vector<LGate> &gates, Plan &plan, bool full_swap) {
+bool build_plan_policy(int n, int p, const std::vector<LGate> &gates, Plan &plan, bool full_swap, int tail) {
     const int P = 1 << p, m = n - p;
     plan.n = n; plan.p = p; plan.m = m;
     std::vector<int> pos(n);
@@ -275,18 +278,18 @@ bool build_plan_policy(int n, int p, const std::vector<LGate> &gates, Plan &plan
             else { blocked |= qs; deferred.push_back(g); }
         }
         if (p && !deferred.empty()) { // an exchange follows: a small last pass waits for it
-            const std::vector<size_t> tail = small_tail(run, pos, m, plan.steps.empty(), tail_limit());
-            if (!tail.empty()) {
+            const std::vector<size_t> tail_gates = small_tail(run, pos, m, plan.steps.empty(), tail);
+            if (!tail_gates.empty()) {
                 std::vector<LGate> keep, moved;
                 size_t t = 0;
                 for (size_t i = 0; i < run.size(); i++) {
-                    if (t < tail.size() && tail[t] == i) { moved.push_back(run[i]); t++; }
+                    if (t < tail_gates.size() && tail_gates[t] == i) { moved.push_back(run[i]); t++; }
                     else keep.push_back(run[i]);
                 }
                 moved.insert(moved.end(), deferred.begin(), deferred.end()); // in front of what was deferred already: nothing there precedes them on a shared qubit
                 deferred.swap(moved);
                 run.swap(keep);
-                plan.tail_gates += (int)tail.size();
+                plan.tail_gates += (int)tail_gates.size();
             }
         }
         for (const LGate &g : run) { // in program order
@@ -319,9 +322,17 @@ bool build_plan_policy(int n, int p, const std::vector<LGate> &gates, Plan &plan
                     }
                 }
             }
-            if (p)
-                for (int r = 0; r < P; r++)
-                    if (holds[(size_t)r]) sup[(size_t)r] = scheduled_support(st.per_shard[(size_t)r], m, sup[(size_t)r]);
+            if (p) {
+                double worst = 0; // the step takes as long as its busiest shard: the first and the last shard stand for all
+                for (int r = 0; r < P; r++) {
+                    if (!holds[(size_t)r]) continue;
+                    double cost = 0;
+                    const bool rep = r == 0 || r == P - 1;
+                    sup[(size_t)r] = scheduled_support(st.per_shard[(size_t)r], m, sup[(size_t)r], rep ? &cost : nullptr);
+                    worst = std::max(worst, cost);
+                }
+                plan.local_sweeps += worst;
+            }
             plan.steps.push_back(std::move(st));
         }
         if (!deferred.empty()) {
@@ -381,12 +392,28 @@ long plan_cost(const Plan &plan) {
 }
 
 // Two placement policies are planned in full and the cheaper plan (by plan_cost) is kept; ties keep the first.
+// One sweep of a shard in plan_cost's units: 2 S bytes at the tile kernel's ~4.5 TB/s against S over a 50 GB/s link = kLinkUnits.
+constexpr double kSweepUnits = 570.0;
+
+// The placement policies (keep far-next-use globals / swap all log2 P of them) and, unless QSIM_SHARD_TAIL pins it, a few
+// limits for the hand-over of a segment's small last pass are planned in full; the plan with the least predicted time — the
+// exchanges over the links (plan_cost) plus the local steps on their busiest shard (Plan::local_sweeps: the segments scheduled
+// with the engine's own scheduler and priced by pass_time_cost) — is kept; ties keep the first.  With QSIM_SHARD_TAIL set only
+// the two policies are compared, by their exchanges alone: the planner proper, which tests/py_shard_plan.py restates.
 bool build_plan(int n, int p, const std::vector<LGate> &gates, Plan &plan) {
-    Plan keep, full;
-    if (!build_plan_policy(n, p, gates, keep, false)) return false;
-    if (p > 1 && build_plan_policy(n, p, gates, full, true) && plan_cost(full) < plan_cost(keep)) plan = std::move(full);
-    else plan = std::move(keep);
-    return true;
+    const bool pinned = getenv("QSIM_SHARD_TAIL") != nullptr;
+    std::vector<int> tails{tail_limit()};
+    if (!pinned && p > 0) for (int t : {0, 12, 40}) tails.push_back(t);
+    bool have = false;
+    double best = 0;
+    for (int tail : tails)
+        for (int full = 0; full < (p > 1 ? 2 : 1); full++) {
+            Plan cand;
+            if (!build_plan_policy(n, p, gates, cand, full != 0, tail)) { if (!have && tail == tails[0] && full == 0) return false; continue; }
+            const double cost = (double)plan_cost(cand) + (pinned ? 0.0 : kSweepUnits * cand.local_sweeps);
+            if (!have || cost < best) { best = cost; plan = std::move(cand); have = true; }
+        }
+    return have;
 }
 
 void gates_of(const qsim_circuit *c, std::vector<LGate> &out) {

@@ -1485,18 +1485,7 @@ static void feed(Scheduler &sched, const qsim_circuit *c) {
     }
 }
 
-// What a pass costs, in bytes moved at the rate of a pass that is bound by its memory traffic.  A tile pass is: up to four
-// merged blocks hide behind the HBM time of the sweep, every further one adds 11 % of it (fp64; fp32 moves half the bytes
-// per amplitude under the same blocks: 20 % from the fourth on).  Fitted on 599 passes of six circuits under six cluster
-// caps at n = 30 (tools/pass_model_data.py, profiles/r03/pass_model_n30.csv): ms = visited x (6.93 + 0.77 x max(0, blocks - 4)),
-// rms error 0.41 ms.  The planning step ranks schedules by the sum of this — fewer sweeps are worth more than leaner ones,
-// but not at any number of blocks.
-static double pass_cost(const Pass &p, bool f32) {
-    if (p.kclass != QSIM_K_TILE) return p.bytes;
-    const int nb = (int)p.blocks.size() - p.geom.n_scale;
-    const double extra = f32 ? 0.20 * std::max(0, nb - 3) : 0.111 * std::max(0, nb - 4);
-    return p.bytes * p.visited * (1.0 + extra);
-}
+static double pass_cost(const Pass &p, bool f32) { return pass_time_cost(p, f32); } // scheduler.h
 
 // Schedules the circuit under a few dozen scheduler settings, remembers the one whose passes are predicted to take the least
 // time (pass_cost) under the key qsim_flush will compute for the same gates on a state with this support, and hands its

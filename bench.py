@@ -379,6 +379,12 @@ class Bench:
 
         cold_ms = None
         if cold and dist is None:
+            # a dozen h gates first: the engine allocates its second buffer and HIP loads the tile kernel on the first tile pass —
+            # 0.04-0.5 s of hipMalloc for 16 GiB depending on the box, which would bury what the figure is about (scheduling and
+            # running the circuit with nothing planned); the CLI figure of `one_shot` includes every allocation
+            from gpu_quantum_simulator_amd import gate_matrix
+            for q in range(3, min(n, 15)):
+                sim.apply_1q(gate_matrix("h"), q)
             self.fence(sim)
             cold_ms = []
             for _ in range(2):

@@ -783,6 +783,17 @@ def test_geometry_planning_keeps_results_and_fills_the_table(oracle, tmp_path):
         assert np.max(np.abs(sim.read() - want)) < TOL
         again = sim.tune(c, max_candidates=6, budget_ms=0)
         assert again["passes_tuned"] == 0 and again["already_known"] == rep["passes_tuned"]
+        # the planning travels: saved, forgotten, loaded — the measured schedule choice ("sched" line) and the geometries are
+        # back, a third planning call measures nothing, and the run is still the oracle's
+        wisdom = str(tmp_path / "wisdom.txt").encode()
+        assert lib.qsim_tune_table_save(wisdom) == 0
+        assert any(ln.startswith("sched ") for ln in open(wisdom.decode()).read().splitlines())
+        lib.qsim_tune_table_clear()
+        assert lib.qsim_tune_table_load(wisdom) == rep["passes_tuned"] + 1
+        third = sim.tune(c, max_candidates=6, budget_ms=0)
+        assert third["passes_tuned"] == 0 and third["candidates_timed"] == 0 and third["already_known"] == rep["passes_tuned"]
+        sim.run(c)
+        assert np.max(np.abs(sim.read() - want)) < TOL
     lib.qsim_tune_table_clear()
     assert lib.qsim_tune_table_size() == 0
 

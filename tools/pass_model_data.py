@@ -4,12 +4,13 @@ from ctypes import byref, c_double
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from gpu_quantum_simulator_amd import Circuit, Simulator, circuits, _lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+precision = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 seeds = [20240117 + n, 1, 2, 3, 4, 5]
 circs = [Circuit.from_gates(n, circuits.random_gates(n, 1000, s, "all")) for s in seeds]
 variants = [{}, {"QSIM_SCHED_CAP": "28"}, {"QSIM_SCHED_CAP": "32"}, {"QSIM_SCHED_CAP": "40"}, {"QSIM_SCHED_CAP": "48"}, {"QSIM_SCHED_CAP": "16"}]
 lib = _lib.load()
 print("visited,blocks,ms")
-with Simulator(n, profile=True) as sim:
+with Simulator(n, profile=True, precision=precision) as sim:
     for env in variants:
         for k in list(os.environ):
             if k.startswith("QSIM_SCHED_"):

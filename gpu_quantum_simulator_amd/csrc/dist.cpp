@@ -241,7 +241,9 @@ int tail_limit() {
     return 24;
 }
 
-bool build_plan_policy(int n, int p, const std::vector<LGate> &gates, Plan &plan, bool full_swap, int tail) {
+// want_cost: also price the local steps (Plan::local_sweeps) — every holding shard's every segment is then scheduled even when
+// its support is already everything; without it only the segments whose support can still grow are (a few at the start of a run).
+bool build_plan_policy(int n, int p, const std::vector<LGate> &gates, Plan &plan, bool full_swap, int tail, bool want_cost) {
     const int P = 1 << p, m = n - p;
     plan.n = n; plan.p = p; plan.m = m;
     std::vector<int> pos(n);
@@ -327,7 +329,7 @@ bool build_plan_policy(int n, int p, const std::vector<LGate> &gates, Plan &plan
                 for (int r = 0; r < P; r++) {
                     if (!holds[(size_t)r]) continue;
                     double cost = 0;
-                    const bool rep = r == 0 || r == P - 1;
+                    const bool rep = want_cost && (r == 0 || r == P - 1);
                     sup[(size_t)r] = scheduled_support(st.per_shard[(size_t)r], m, sup[(size_t)r], rep ? &cost : nullptr);
                     worst = std::max(worst, cost);
                 }
@@ -402,15 +404,19 @@ constexpr double kSweepUnits = 570.0;
 // the two policies are compared, by their exchanges alone: the planner proper, which tests/py_shard_plan.py restates.
 bool build_plan(int n, int p, const std::vector<LGate> &gates, Plan &plan) {
     const bool pinned = getenv("QSIM_SHARD_TAIL") != nullptr;
+    // the search schedules every segment of every candidate plan: seconds for the circuits it is meant for (thousands of
+    // gates on registers that need many GPUs), minutes for a 400 000-gate file like the reference's own benchmark circuits
+    // (OverallTest.csv) — those get the default plan
+    const bool search = !pinned && p > 0 && gates.size() <= 20000;
     std::vector<int> tails{tail_limit()};
-    if (!pinned && p > 0) for (int t : {0, 12, 40}) tails.push_back(t);
+    if (search) for (int t : {0, 12, 40}) tails.push_back(t);
     bool have = false;
     double best = 0;
     for (int tail : tails)
         for (int full = 0; full < (p > 1 ? 2 : 1); full++) {
             Plan cand;
-            if (!build_plan_policy(n, p, gates, cand, full != 0, tail)) { if (!have && tail == tails[0] && full == 0) return false; continue; }
-            const double cost = (double)plan_cost(cand) + (pinned ? 0.0 : kSweepUnits * cand.local_sweeps);
+            if (!build_plan_policy(n, p, gates, cand, full != 0, tail, search)) { if (!have && tail == tails[0] && full == 0) return false; continue; }
+            const double cost = (double)plan_cost(cand) + (search ? kSweepUnits * cand.local_sweeps : 0.0);
             if (!have || cost < best) { best = cost; plan = std::move(cand); have = true; }
         }
     return have;

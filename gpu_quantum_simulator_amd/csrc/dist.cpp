@@ -36,6 +36,7 @@ struct LGate { // logical gate
     int kind;  // QSIM_GATE_U1 / QSIM_GATE_CX
     int q0, q1;
     cd m[4];
+    long idx = 0; // position in the circuit
     bool diag() const { return m[1] == cd(0, 0) && m[2] == cd(0, 0); }
 };
 
@@ -280,7 +281,38 @@ bool build_plan_policy(int n, int p, const std::vector<LGate> &gates, Plan &plan
             else { blocked |= qs; deferred.push_back(g); }
         }
         if (p && !deferred.empty()) { // an exchange follows: a small last pass waits for it
-            const std::vector<size_t> tail_gates = small_tail(run, pos, m, plan.steps.empty(), tail);
+            // What the scheduler put into the last pass is only a PROPOSAL: it saw one shard's version of the segment (a CX controlled
+            // by a shard-id bit as an X; on the shards where that bit is 0 there is no gate at all, and products that cancel on one
+            // shard do not on another), so its order proves nothing for the others.  A gate may wait for the exchange if it
+            // commutes, by what it IS — not by what some product of matrices happens to be —, with every gate of the segment
+            // that comes after it in the circuit and stays: no shared qubit, or only qubits in which both are block-diagonal
+            // (a diagonal gate, the control of a CX).  Gates that fail stay, which can make others fail: iterate.
+            std::vector<size_t> tail_gates = small_tail(run, pos, m, plan.steps.empty(), tail);
+            {
+                auto diag_mask = [](const LGate &g) -> uint64_t { // qubits the gate is block-diagonal in
+                    if (g.kind == QSIM_GATE_CX) return g.q0 == g.q1 ? 0 : 1ULL << g.q0;
+                    return g.diag() ? 1ULL << g.q0 : 0;
+                };
+                auto qubits = [](const LGate &g) -> uint64_t { return (1ULL << g.q0) | (g.kind == QSIM_GATE_CX ? 1ULL << g.q1 : 0); };
+                std::vector<char> moving(run.size(), 0);
+                for (size_t t : tail_gates) moving[t] = 1;
+                for (bool changed = true; changed;) {
+                    changed = false;
+                    uint64_t later_mix = 0, later_any = 0; // over the staying gates behind the current position: qubits they mix / touch
+                    for (size_t i = run.size(); i-- > 0;) {
+                        const LGate &g = run[i];
+                        const uint64_t q = qubits(g), d = diag_mask(g);
+                        if (moving[i]) {
+                            // shared qubits must be diagonal on both sides: none of g's qubits may be mixed later, none of g's mixed qubits touched later
+                            if ((q & later_mix) || ((q & ~d) & later_any)) { moving[i] = 0; changed = true; }
+                        }
+                        if (!moving[i]) { later_mix |= q & ~d; later_any |= q; }
+                    }
+                }
+                tail_gates.clear();
+                for (size_t i = 0; i < run.size(); i++)
+                    if (moving[i]) tail_gates.push_back(i);
+            }
             if (!tail_gates.empty()) {
                 std::vector<LGate> keep, moved;
                 size_t t = 0;
@@ -427,7 +459,7 @@ void gates_of(const qsim_circuit *c, std::vector<LGate> &out) {
     for (long i = 0; i < c->count; i++) {
         const qsim_gate_rec &g = c->gates[i];
         LGate lg{};
-        lg.kind = g.kind; lg.q0 = g.q0; lg.q1 = g.q1;
+        lg.kind = g.kind; lg.q0 = g.q0; lg.q1 = g.q1; lg.idx = i;
         if (g.kind == QSIM_GATE_U1)
             for (int k = 0; k < 4; k++) lg.m[k] = cd(c->mats2[8 * (long)g.mat + 2 * k], c->mats2[8 * (long)g.mat + 2 * k + 1]);
         out.push_back(lg);

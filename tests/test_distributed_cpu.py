@@ -270,6 +270,37 @@ def test_small_last_pass_waits_for_the_exchange(oracle, tmp_path, world, monkeyp
         assert sweeps["24"] <= sweeps["0"] - 1.0  # 14 -> 12 sweeps of the shard
 
 
+def test_hand_over_is_checked_gate_by_gate(oracle, tmp_path, monkeypatch):
+    """The last pass the engine's scheduler proposes for a segment is one shard's view: a CX controlled by a shard-id bit is an X
+    there and nothing on the shards where the bit is 0, and products that cancel in one view (h x h x = 1: the cluster vanishes
+    and no longer orders anything) do not in another.  A stress case of round 3 (n = 16, 88 gates, 4 shards) handed over a CX and
+    a diagonal gate across three later non-diagonal gates on the same qubit: amplitudes off by 0.04.  The planner now moves a gate
+    only if it commutes, by what it is, with every later gate of the segment that stays.  That case, and 36 seeded others with
+    shards of >= 2^12 amplitudes (where the hand-over is active), against the oracle."""
+    monkeypatch.setenv("QSIM_SHARD_TAIL", "24")
+    cases = [(16, 88, 9424, "all", 4)]
+    rng = np.random.default_rng(5)
+    for k in range(36):
+        world = int(rng.choice([2, 4, 8]))
+        cases.append((int(rng.integers(12 + world.bit_length() - 1, 16)), int(rng.integers(40, 260)), 31000 + k,
+                      "all" if rng.random() < 0.7 else "clifford_t", world))
+    moved_any = False
+    for n, depth, seed, vocab, world in cases:
+        path = circuits.random_circuit_file(str(tmp_path / "c.qasm"), n, depth, seed, vocab)
+        _, want, _, _ = oracle.run_qasm(path)
+        from gpu_quantum_simulator_amd import Circuit
+        c = Circuit.from_file(path)
+        gates = [c.gate(i) for i in range(len(c))]
+        vc = VirtualCluster(n, world, gates, shard_factory=CpuShard)
+        vc.run()
+        assert np.max(np.abs(vc.gather_logical() - want)) < TOL, (n, depth, seed, vocab, world)
+        monkeypatch.setenv("QSIM_SHARD_TAIL", "0")
+        plain = [len(st[1]) for st in ShardPlan(n, world.bit_length() - 1, normalize_gates(gates, gate_matrix), world - 1).steps if st[0] == "local"]
+        monkeypatch.setenv("QSIM_SHARD_TAIL", "24")
+        moved_any = moved_any or [len(st[1]) for st in vc.plans[world - 1].steps if st[0] == "local"] != plain
+    assert moved_any  # the hand-over did happen in some of them
+
+
 def test_launcher_spawns_ranks_as_children():
     """bench.py --gpus N (no external launcher) starts its ranks through launch.spawn_ranks: here 2 gloo ranks of a
     probe script go through the same function; the parent relays rank 0's line and the exit code."""

@@ -15,6 +15,8 @@ with tempfile.TemporaryDirectory() as d:
                 "plan_cache": int(rng.integers(0, 2)), "pingpong": int(rng.choice([0, 2])), "sparse_start": int(rng.integers(0, 2)),
                 "debug_plan_key": int(rng.choice([0, 0, 77]))}
         kind = rng.random()
+        if os.environ.get("STRESS_KIND") == "cluster":
+            kind = 0.9  # only sharded cases (same random stream otherwise)
         if kind < 0.85:
             continue
         P = int(rng.choice([2, 4, 8])); n = int(rng.integers(14, 20))

@@ -348,7 +348,8 @@ def _pack_np(state, m, Lsel):
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
-@pytest.mark.parametrize("n,depth,seed,vocab", [(7, 120, 21, "all"), (10, 400, 22, "all"), (12, 500, 23, "clifford_t"), (11, 60, 24, "all")])
+@pytest.mark.parametrize("n,depth,seed,vocab", [(7, 120, 21, "all"), (10, 400, 22, "all"), (12, 500, 23, "clifford_t"), (11, 60, 24, "all"),
+                                                (15, 260, 25, "all"), (15, 120, 26, "clifford_t"), (16, 88, 9424, "all")])  # shards of >= 2^12: the hand-over is active
 def test_sparse_exchange_protocol_on_poisoned_memory(oracle, tmp_path, world, n, depth, seed, vocab):
     """What an exchange may leave out (csrc/dist.cpp roles_of; qsim_shard_plan_exchange_roles): shards that hold nothing
     neither pack nor send, blocks that are zero throughout are not received, and a receiver only ever looks inside its

@@ -55,7 +55,7 @@ with tempfile.TemporaryDirectory() as d:
             with Cluster(n, P, devices=[0] * P, pingpong=opts["pingpong"], tile_bits=int(rng.choice([9, 12]))) as cl:
                 cl.run(stale)
                 if rng.random() < 0.5:
-                    cl.plan(c)
+                    cl.plan(c, int(rng.choice([1, 1, 4])), 300.0)  # schedule choice per shard; sometimes with timing (measured choice + tile-bit orders)
                 for rep in range(2):
                     cl.run(c)
                     err = float(np.max(np.abs(cl.read() - want)))

@@ -21,6 +21,7 @@ with tempfile.TemporaryDirectory() as d:
             continue
         P = int(rng.choice([2, 4, 8])); n = int(rng.integers(14, 20))
         tail = int(rng.choice([0, 8, 24])); tb = int(rng.choice([9, 12])); do_plan = rng.random() < 0.5
+        plan_cand = int(rng.choice([1, 1, 4])) if do_plan else 1
         if case != target:
             continue
         print("case", case, "n", n, "depth", depth, vocab, "P", P, "tail", tail, "tile_bits", tb, "plan", do_plan, "pingpong", opts["pingpong"], flush=True)
@@ -36,7 +37,7 @@ with tempfile.TemporaryDirectory() as d:
                 if variant != "no stale run":
                     cl.run(stale)
                 if do_plan and variant != "no plan":
-                    cl.plan(c)
+                    cl.plan(c, plan_cand, 300.0)
                 for rep in range(2):
                     cl.run(c)
                     err = float(np.max(np.abs(cl.read() - want)))

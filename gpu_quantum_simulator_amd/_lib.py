@@ -142,6 +142,7 @@ SIGNATURES = {
     "qsim_choose_schedule": (c_int, [c_void_p, c_void_p]),
     "qsim_tune_circuit_from": (c_int, [c_void_p, c_void_p, c_int, c_double, POINTER(QsimTuneReport), c_int]),
     "qsim_choose_schedule_for": (c_int, [c_void_p, c_void_p, c_uint64]),
+    "qsim_support_after": (c_int, [c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]),
     "qsim_tune_circuit_support": (c_int, [c_void_p, c_void_p, c_int, c_double, POINTER(QsimTuneReport), c_uint64]),
     "qsim_cluster_plan": (c_int, [c_void_p, c_void_p, c_int, c_double]),
     "qsim_tune_table_size": (c_long, []),

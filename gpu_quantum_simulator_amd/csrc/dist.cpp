@@ -904,13 +904,49 @@ static int cluster_plan_for(qsim_cluster *c, const qsim_circuit *circ) {
     return QSIM_OK;
 }
 
+// Schedule choice (and, with max_candidates > 1, timing) for every shard's every local step, step by step for all shards, so
+// that each exchange can be told what its senders' engines will actually have written by then: a schedule chosen here may
+// leave other qubits untouched than the default one the planner assumed, and the last tile pass in front of an exchange does
+// the re-layout itself only when what it writes covers what the receivers look at (Step::mixed_local).  Both masks bound
+// the same state, so their intersection does too; holders and supports after the exchange follow from it.
 extern "C" int qsim_cluster_plan(qsim_cluster *c, const qsim_circuit *circ, int max_candidates, double budget_ms) {
     if (!c || !circ) return cfail(QSIM_ERR_ARG, "NULL argument");
     int rc = cluster_plan_for(c, circ);
     if (rc) return rc;
-    for (int r = 0; r < c->P; r++) {
-        rc = plan_shard_steps(c->planned, r, c->shard[r], max_candidates, budget_ms > 0 ? budget_ms / c->P : 0.0, nullptr);
-        if (rc) return rc;
+    Plan &plan = c->planned;
+    int locals = 0;
+    for (const Step &st : plan.steps) locals += !st.exchange;
+    const double budget_each = budget_ms > 0 && locals > 0 ? budget_ms / c->P / locals : 0.0;
+    std::vector<uint64_t> sup((size_t)c->P, 0);
+    std::vector<char> holds((size_t)c->P, 0);
+    holds[0] = 1;
+    for (Step &st : plan.steps) {
+        if (st.exchange) {
+            uint64_t written = 0, ranks = 0;
+            for (int r = 0; r < c->P; r++)
+                if (holds[(size_t)r]) { written |= sup[(size_t)r]; ranks |= (uint64_t)r; }
+            st.mixed_local &= written;
+            st.mixed_rank &= ranks;
+            for (int r = 0; r < c->P; r++) {
+                const Roles ro = roles_of(r, plan.m, st);
+                holds[(size_t)r] = !ro.empty_after;
+                sup[(size_t)r] = ro.empty_after ? 0 : ro.new_support;
+            }
+            continue;
+        }
+        for (int r = 0; r < c->P; r++) {
+            if (!holds[(size_t)r]) continue;
+            qsim_circuit *sc = nullptr;
+            rc = step_circuit(st, r, plan.m, &sc);
+            if (rc == QSIM_OK) {
+                qsim_tune_report rep{};
+                if (max_candidates > 1) rc = qsim_tune_circuit_support(c->shard[r], sc, max_candidates, budget_each, &rep, sup[(size_t)r]);
+                else rc = qsim_choose_schedule_for(c->shard[r], sc, sup[(size_t)r]);
+            }
+            if (rc == QSIM_OK) rc = qsim_support_after(c->shard[r], sc, sup[(size_t)r], &sup[(size_t)r]);
+            qsim_circuit_free(sc);
+            if (rc) return cfail(rc, "%s", qsim_last_error());
+        }
     }
     return qsim_cluster_reset(c);
 }

@@ -883,11 +883,17 @@ static bool have_sched_hints() {
 // long as job->needed (where the receivers expect data) lies inside it; else the pack kernel does the job (it writes zeros).
 // support_before: where the state can be non-zero when the pass starts (current_support() once every earlier pass has been launched).
 static bool pass_can_pack(const qsim_state *s, const Pass &p, const TileGeom &geom, const PackJob *job, uint64_t support_before) {
-    if (p.kclass != QSIM_K_TILE || s->debug_skip_ops || s->debug_skip_mem || !launch_tile_can_pack(s->f32, geom, s->tile_threads)) return false;
+    static const bool trace = getenv("QSIM_TRACE_PACK") != nullptr; // says on stderr why a re-layout got its own sweep
+    if (p.kclass != QSIM_K_TILE || s->debug_skip_ops || s->debug_skip_mem || !launch_tile_can_pack(s->f32, geom, s->tile_threads)) {
+        if (trace) fprintf(stderr, "qsim: re-layout not fused: last pass is %s\n", p.kclass != QSIM_K_TILE ? "no tile pass" : "a tile pass without the packing variant");
+        return false;
+    }
     const uint64_t nmask = s->n >= 64 ? ~0ULL : ((1ULL << s->n) - 1ULL);
     uint64_t after = (1ULL << geom.low_bits) - 1ULL;
     for (int j = 0; j < geom.n_high; j++) after |= 1ULL << geom.high[j];
     after |= support_before;
+    if (trace && ((job->needed & nmask) & ~after) != 0)
+        fprintf(stderr, "qsim: re-layout not fused: the pass writes support %llx, the receivers look at %llx\n", (unsigned long long)(after & nmask), (unsigned long long)(job->needed & nmask));
     return ((job->needed & nmask) & ~after) == 0;
 }
 static uint64_t current_support(const qsim_state *s);
@@ -1351,6 +1357,7 @@ extern "C" int qsim_flush_pack(qsim_state *s, const int *bits, int nbits, const 
         for (int j = 0; j < nbits; j++) at |= (uint64_t)((b >> j) & 1) << job.map.to[j];
         blocks[b] = dst + 16 * at;
     }
+    if (getenv("QSIM_TRACE_PACK")) fprintf(stderr, "qsim: re-layout by the pack kernel (n = %d, support %llx)\n", s->n, (unsigned long long)current_support(s));
     rc = pack_common(s, bits, nbits, nullptr, blocks, true, skip_blocks);
     if (rc) return rc;
     if (packed_at) *packed_at = dst;
@@ -1513,6 +1520,19 @@ static void set_sched_hint(uint64_t key, const SchedHint &now, bool is_default, 
         g_wisdom_epoch++; // cached plans of this circuit were scheduled another way
 }
 
+// The circuit as the gate queue qsim_run_circuit would leave in a state (what the plan and schedule-hint keys are computed from).
+static std::vector<QueuedGate> queue_of(const qsim_circuit *c) {
+    std::vector<QueuedGate> q((size_t)c->count);
+    for (long i = 0; i < c->count; i++) {
+        const qsim_gate_rec &g = c->gates[i];
+        QueuedGate &o = q[(size_t)i];
+        o.kind = g.kind; o.q0 = g.q0; o.q1 = g.kind == QSIM_GATE_U1 ? -1 : g.q1;
+        const double *U = g.kind == QSIM_GATE_U1 ? c->mats2 + 8 * (long)g.mat : g.kind == QSIM_GATE_CX ? nullptr : c->mats4 + 32 * (long)g.mat;
+        for (int k = 0; U && k < (g.kind == QSIM_GATE_U1 ? 4 : 16); k++) o.m[k] = cd(U[2 * k], U[2 * k + 1]);
+    }
+    return q;
+}
+
 static void choose_schedule(qsim_state *s, const qsim_circuit *c, const SchedConfig &scfg, std::vector<Pass> *out,
                             std::vector<RankedVariant> *ranked = nullptr, uint64_t *key_out = nullptr) {
     std::vector<Pass> passes;
@@ -1523,14 +1543,7 @@ static void choose_schedule(qsim_state *s, const qsim_circuit *c, const SchedCon
         if (out) *out = std::move(passes);
         return;
     }
-    std::vector<QueuedGate> q((size_t)c->count);
-    for (long i = 0; i < c->count; i++) {
-        const qsim_gate_rec &g = c->gates[i];
-        QueuedGate &o = q[(size_t)i];
-        o.kind = g.kind; o.q0 = g.q0; o.q1 = g.kind == QSIM_GATE_U1 ? -1 : g.q1;
-        const double *U = g.kind == QSIM_GATE_U1 ? c->mats2 + 8 * (long)g.mat : g.kind == QSIM_GATE_CX ? nullptr : c->mats4 + 32 * (long)g.mat;
-        for (int k = 0; U && k < (g.kind == QSIM_GATE_U1 ? 4 : 16); k++) o.m[k] = cd(U[2 * k], U[2 * k + 1]);
-    }
+    const std::vector<QueuedGate> q = queue_of(c);
     const uint64_t key = gates_key(s, plan_identity(s, q.size(), scfg.initial_support), q.data(), q.size());
     // the variants: how many clusters a pass may take (where the engine sets a cap of its own: states of 4 GiB and more),
     // clusters may / may not overtake (commute), how eagerly passes inside the support are kept (cheap_margin), one more
@@ -1625,6 +1638,34 @@ extern "C" int qsim_choose_schedule_for(qsim_state *s, const qsim_circuit *c, ui
     else support &= nmask;
     const SchedConfig scfg = sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32, support);
     choose_schedule(s, c, scfg, nullptr);
+    return QSIM_OK;
+}
+
+// Where a state that has this support can be non-zero after the circuit, as THIS engine will know it then: the circuit is
+// scheduled the way qsim_flush will schedule the same gates (same options, same remembered schedule choice) and every tile pass
+// adds its tile qubits; a single-gate kernel makes the state dense.  A cluster's planner derives from it what an exchange's
+// receivers look at, so that the sender's last tile pass — which writes exactly this — can do the re-layout itself.
+extern "C" int qsim_support_after(qsim_state *s, const qsim_circuit *c, uint64_t support, uint64_t *after) {
+    if (!s || !c || !after) return fail(QSIM_ERR_ARG, "NULL argument");
+    if (c->num_q != s->n) return fail(QSIM_ERR_ARG, "circuit has %d qubits, state has %d", c->num_q, s->n);
+    const uint64_t nmask = s->n >= 64 ? ~0ULL : ((1ULL << s->n) - 1ULL);
+    if (!s->sparse_start || (support & nmask) == nmask) { *after = nmask; return QSIM_OK; }
+    support &= nmask;
+    if (c->count == 0) { *after = support; return QSIM_OK; }
+    SchedConfig scfg = sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32, support);
+    if (s->fuse >= 3 && have_sched_hints()) {
+        const std::vector<QueuedGate> q = queue_of(c);
+        apply_sched_hint(gates_key(s, plan_identity(s, q.size(), support), q.data(), q.size()), scfg);
+    }
+    Scheduler sv(scfg);
+    feed(sv, c);
+    uint64_t sup = support;
+    sv.finish([&](Pass &&p) {
+        if (p.kclass != QSIM_K_TILE) { sup = nmask; return; } // the engine writes the zeros out first (materialize_zero_ket)
+        sup |= (1ULL << p.geom.low_bits) - 1ULL;
+        for (int j = 0; j < p.geom.n_high; j++) sup |= 1ULL << p.geom.high[j];
+    });
+    *after = sup & nmask;
     return QSIM_OK;
 }
 

@@ -250,6 +250,14 @@ class Simulator:
         """qsim_set_support: amplitudes whose index has a bit outside `support` are zero by definition from now on."""
         check(_lib.load().qsim_set_support(self._h, support))
 
+    def support_after(self, circuit: Circuit, support: int = 0) -> int:
+        """qsim_support_after: where the state can be non-zero after `circuit` ran on a state with this support, as the engine
+        will track it (scheduled as a flush would schedule it; nothing runs)."""
+        from ctypes import c_uint64
+        out = c_uint64()
+        check(_lib.load().qsim_support_after(self._h, circuit._h, support & 0xFFFFFFFFFFFFFFFF, byref(out)))
+        return int(out.value)
+
     def get_support(self):
         """(support mask, pending basis state?, its amplitude) — qsim_get_support."""
         from ctypes import c_uint64

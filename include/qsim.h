@@ -198,6 +198,9 @@ int qsim_tune_circuit_from(qsim_state *s, const qsim_circuit *circuit, int max_c
 /* Both for a run that finds the state with exactly the support `support` (index bits that may be 1: 0 fresh from a reset, all
  * ones dense, the mask given to qsim_set_support after a sparse exchange): a shard's local steps between exchanges. */
 int qsim_choose_schedule_for(qsim_state *s, const qsim_circuit *circuit, uint64_t support);
+/* Index bits that may be 1 somewhere in the state after `circuit` ran on a state with support `support`, as the engine itself
+ * will track it (the circuit is scheduled as qsim_flush will schedule it, remembered schedule choice included; nothing runs). */
+int qsim_support_after(qsim_state *s, const qsim_circuit *circuit, uint64_t support, uint64_t *after);
 int qsim_tune_circuit_support(qsim_state *s, const qsim_circuit *circuit, int max_candidates, double budget_ms, qsim_tune_report *report, uint64_t support);
 long qsim_tune_table_size(void);
 void qsim_tune_table_clear(void);

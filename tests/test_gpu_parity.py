@@ -1234,6 +1234,55 @@ def test_cluster_exchanges_leave_out_what_is_zero(oracle, tmp_path, shards):
             assert fused + separate > 0 and (depth != 700 or fused > 0)  # most re-layouts ride on the last tile pass before the exchange
 
 
+@pytest.mark.parametrize("planned", [False, True])
+def test_support_after_is_what_the_engine_ends_up_with(tmp_path, planned):
+    """qsim_support_after predicts, without running anything, the support the engine tracks after a circuit — with the default
+    schedule and with the one the planning step chose — from a reset and from a partial support."""
+    n = 20
+    for seed, depth in ((1, 6), (2, 14), (3, 40), (4, 200)):
+        gates = [g for g in circuits.random_gates(n, depth, 900 + seed, "all") if seed == 4 or max(g[1:] if g[0] == "cx" else g[-1:]) < n - 2]
+        c = Circuit.from_gates(n, gates)
+        with Simulator(n, fuse=3) as sim:
+            if planned:
+                sim.choose_schedule(c)
+            want = sim.support_after(c, 0)
+            sim.run(c)
+            sim.flush()
+            got, pending, _ = sim.get_support()
+            assert not pending and got == want, (seed, hex(got), hex(want))
+            if got != (1 << n) - 1:  # some qubit is still |0>: a second circuit on top of the partial state
+                c2 = Circuit.from_gates(n, circuits.random_gates(n, 10, 950 + seed, "all"))
+                want2 = sim.support_after(c2, got)
+                sim.run(c2)
+                sim.flush()
+                assert sim.get_support()[0] == want2
+
+
+@pytest.mark.parametrize("shards", [2, 4])
+def test_planned_cluster_lets_the_last_pass_do_every_relayout(oracle, tmp_path, shards):
+    """qsim_cluster_plan goes through the steps in order and tells every exchange what its senders' engines will have written
+    under the schedules it chose (qsim_support_after), so the last tile pass in front of an exchange can take the re-layout
+    also where the chosen schedule leaves other qubits untouched than the planner's default one.  Same amplitudes as the
+    oracle; with planning at most as many separate pack sweeps as without."""
+    from gpu_quantum_simulator_amd import Cluster
+    n = 18
+    for seed in (11, 12, 13):
+        path = circuits.random_circuit_file(str(tmp_path / f"p{seed}.qasm"), n, 600, seed, "all")
+        _, want, _, _ = oracle.run_qasm(path)
+        c = Circuit.from_file(path)
+        counts = []
+        for plan in (False, True):
+            with Cluster(n, shards, devices=[0] * shards) as cl:
+                if plan:
+                    cl.plan(c)
+                cl.run(c)
+                assert np.max(np.abs(cl.read() - want)) < TOL
+                counts.append(cl.pack_counts())
+                cl.run(c)  # the cached plan (refined by the planning step) a second time
+                assert np.max(np.abs(cl.read() - want)) < TOL
+        assert counts[1][1] <= counts[0][1], counts
+
+
 def _pack_src_index(n, bits):
     k = len(bits)
     d = np.arange(1 << n, dtype=np.int64)

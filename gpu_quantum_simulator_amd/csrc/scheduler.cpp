@@ -143,8 +143,8 @@ SchedConfig engine_sched_config(int n, int fuse, int tile_bits, int tile_low_bit
     c.pad_from = pad_from;
     c.initial_support = initial_support; // 0: the run starts from a reset (what the planning entry points assume)
     c.n = n; c.fuse = fuse; c.tile_bits = tile_bits; c.tile_low_bits = tile_low_bits; c.tile_max_ops = tile_max_ops;
-    // The pass-set local search (SchedConfig::local_iters with one pass of lookahead) costs ~1.5 ms of host time per
-    // pass.  Passes are launched as they are produced, so the search is free once a pass runs longer than that on the
+    // The pass-set local search (SchedConfig::local_iters with one pass of lookahead) cost ~1.5 ms of host time per pass when the
+    // thresholds below were measured (~0.7 ms since the scans of build_passes became incremental).  Passes are launched as they are produced, so the search is free once a pass runs longer than that on the
     // GPU: from 4 GiB of state (n = 28 fp64: 1.9 ms per pass).  Since the row-class form of the sparse blocks (one LDS
     // read per amplitude) most passes are bound by their memory time again, so one pass less is ~7 ms less at n = 30
     // (round 1: the fuller passes were LDS-bound and the total did not move).  With the search on, a pass is capped at
@@ -671,7 +671,7 @@ void Scheduler::build_passes(const PassSink &sink) {
     // no new qubit (scan's early return) changes nothing for the clusters in front of it — the scan simply goes on behind
     // it with the blocked qubits and the cheapest candidate seen so far; only a pick that admits a qubit (it comes after a
     // whole scan) changes what the others need, and the next scan starts over.  (The local search fills ~4000 trial passes
-    // per schedule this way: 34 -> 14 ms of host time for the 1000 gates of the bench circuit.)
+    // per schedule this way; with the pruned local search below 34 -> 15.6 ms of host time for the 1000 gates of the bench circuit.)
     auto fill = [&](std::vector<char> &dn, size_t from, size_t to, uint64_t &hset, int limit) {
         int cnt = 0;
         size_t i = from;

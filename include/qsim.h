@@ -282,7 +282,10 @@ int qsim_cluster_sync(qsim_cluster *c);
 /* Planning for a circuit the cluster will run (repeatedly): the shard plan is built and kept, and every shard's local steps go
  * through the schedule choice of qsim_choose_schedule — and, with max_candidates > 1, through the measured tile-bit orders of
  * qsim_tune_circuit (budget_ms for all shards together, 0 = unbounded) — each for the support the shard will have at that
- * point of the run.  Outside any timed region; results never depend on it.  Leaves the cluster reset. */
+ * point of the run.  The steps are planned in order for all shards, and every exchange of the kept plan is told what its
+ * senders will have written under the schedules chosen (qsim_support_after), so that their last tile pass can do the
+ * re-layout.  Outside any timed region; results never depend on it.  Leaves the cluster reset.
+ * QSIM_TRACE_PACK=1 in the environment: one line on stderr for every re-layout that needed a sweep of its own, with the reason. */
 int qsim_cluster_plan(qsim_cluster *c, const qsim_circuit *circuit, int max_candidates, double budget_ms);
 int qsim_cluster_read(qsim_cluster *c, uint64_t logical_first, uint64_t count, double *out_re_im);
 int qsim_cluster_norm2(qsim_cluster *c, double *out);

@@ -1,4 +1,5 @@
-"""One-off randomised parity stress (not part of the test suite): many seeded circuits x engine options (tile shape, ops
+"""Randomised parity stress, run by hand on the GPU box (python tests/stress_parity.py CASES SEED; not collected by pytest; it lives
+under tests/ because it calls the oracle): many seeded circuits x engine options (tile shape, ops
 per pass, shuffled tile-bit orders, plan cache on/off, out-of-place passes, sparse start, fp32, virtual-shard clusters)
 against the oracle."""
 import os

@@ -1,4 +1,4 @@
-"""Replays tools/stress_parity.py's random stream up to one case and runs only that case, verbosely.  Usage: stress_repro.py CASE SEED"""
+"""Replays tests/stress_parity.py's random stream up to one case and runs only that case, verbosely.  Usage: stress_repro.py CASE SEED"""
 import os, sys, tempfile
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np

@@ -92,6 +92,7 @@ SIGNATURES = {
     "qsim_set_spare_buffer": (c_int, [c_void_p, c_void_p]),
     "qsim_set_support": (c_int, [c_void_p, c_uint64]),
     "qsim_get_support": (c_int, [c_void_p, POINTER(c_uint64), POINTER(c_int), _DP]),
+    "qsim_holds_nothing": (c_int, [c_void_p]),
     "qsim_pack_bits_sparse": (c_int, [c_void_p, POINTER(c_int), c_int, c_void_p, POINTER(c_void_p), ctypes.c_uint32]),
     "qsim_state_buffer": (c_void_p, [c_void_p]),
     "qsim_flush_pack": (c_int, [c_void_p, POINTER(c_int), c_int, POINTER(c_int), c_uint64, c_void_p, c_uint64, ctypes.c_uint32, POINTER(c_void_p), POINTER(c_int)]),

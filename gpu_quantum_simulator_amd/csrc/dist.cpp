@@ -134,9 +134,10 @@ struct Roles {
     uint32_t unread = 0;         // blocks of this rank's packed layout nobody looks at
     uint64_t new_support = 0;
 };
+constexpr int kMaxRoleBits = 5; // Roles::send / recv / unread and k_pack's skip mask have one bit per block: groups of at most 32 shards
 Roles roles_of(int rank, int m, const Step &st) {
     Roles r;
-    const int k = (int)st.J.size();
+    const int k = (int)st.J.size(); // callers bound k by kMaxRoleBits (exchange, rank_exchange, the planner's P <= 32)
     peers_of(rank, st.J, r.mine, r.members);
     uint32_t jmask = 0, jin = 0, lin = 0;
     uint64_t lsel = 0;
@@ -493,6 +494,9 @@ struct qsim_cluster {
     int planned_tail = -1;
     uint64_t fused_packs = 0, separate_packs = 0;
     std::vector<hipEvent_t> packed; // per shard: its pack of the current exchange has finished
+    // A plan is only right from |0...0>: its first qubit placement is free BECAUSE that state is permutation-symmetric, and its
+    // exchanges leave out what is zero from there (Step::mixed_*).  Set by qsim_cluster_reset, cleared when a circuit starts.
+    bool fresh = false;
 };
 
 static thread_local std::string g_derr;
@@ -630,6 +634,7 @@ extern "C" int qsim_cluster_reset(qsim_cluster *c) {
         if (rc) return cfail(rc, "%s", qsim_last_error());
     }
     for (int q = 0; q < c->n; q++) c->pos[q] = q;
+    c->fresh = true;
     return QSIM_OK;
 }
 
@@ -787,6 +792,7 @@ static int exchange_copies(qsim_cluster *c, const Step &st) {
 static int exchange(qsim_cluster *c, const Step &st) {
     const int k = (int)st.J.size();
     int rc;
+    if (k > kMaxRoleBits && !c->comms.empty()) return cfail(QSIM_ERR_ARG, "exchange of %d qubits: groups of more than %d shards are not supported on RCCL", k, 1 << kMaxRoleBits);
     if (!c->comms.empty()) rc = exchange_rccl(c, st);
     else if (c->same_device && k <= 3) rc = exchange_direct(c, st);
     else rc = exchange_copies(c, st);
@@ -802,16 +808,21 @@ extern "C" const char *qsim_cluster_exchange_mode(const qsim_cluster *c) {
     return !c->comms.empty() ? "rccl" : c->same_device ? "direct" : "copies";
 }
 
-// Plans and runs the circuit from the CURRENT state with the map reset to what the planner assumes, i.e. call
-// qsim_cluster_reset first (compute_state_vector semantics: one circuit per state).
+// Plans and runs ONE circuit from |0...0> (compute_state_vector semantics, quantum_simulator.c:115-254: one circuit per
+// state): qsim_cluster_reset must come first.  The plan depends on it twice — the first qubit placement moves no data because
+// |0...0> is permutation-symmetric, and the exchanges neither send nor read what is still zero (Step::mixed_*, roles_of) — so
+// a second circuit on top of the first one's result, or on a state the caller wrote through qsim_cluster_shard(), is refused
+// instead of silently dropping amplitudes.
 static int cluster_plan_for(qsim_cluster *c, const qsim_circuit *circ);
 static int plan_shard_steps(const Plan &plan, int shard, qsim_state *s, int max_candidates, double budget_ms, qsim_tune_report *total);
 
 extern "C" int qsim_cluster_run_circuit(qsim_cluster *c, const qsim_circuit *circ) {
     if (!c || !circ) return cfail(QSIM_ERR_ARG, "NULL argument");
     if (circ->num_q != c->n) return cfail(QSIM_ERR_ARG, "circuit has %d qubits, cluster has %d", circ->num_q, c->n);
+    if (!c->fresh) return cfail(QSIM_ERR_ARG, "cluster does not hold |0...0>: qsim_cluster_run_circuit runs one circuit per reset (call qsim_cluster_reset first)");
     for (int q = 0; q < c->n; q++)
         if (c->pos[q] != q) return cfail(QSIM_ERR_ARG, "cluster already holds a permuted state: reset it first");
+    c->fresh = false;
     {
         const int rc = cluster_plan_for(c, circ);
         if (rc) return rc;
@@ -1297,10 +1308,14 @@ extern "C" int qsim_rank_comm_create(qsim_rank_comm **out, qsim_state *shard, in
 static int rank_exchange(qsim_rank_comm *c, const Step &st) {
     const int k = (int)st.J.size();
     const int m = qsim_num_qubits(c->shard);
-    if (k < 1 || k > m || (1 << k) > c->world) return cfail(QSIM_ERR_ARG, "exchange of %d qubits unsupported here", k);
+    if (k < 1 || k > m || k > kMaxRoleBits || (1 << k) > c->world) return cfail(QSIM_ERR_ARG, "exchange of %d qubits unsupported here (at most %d: groups of %d ranks)", k, kMaxRoleBits, 1 << kMaxRoleBits);
     for (int j : st.J)
         if (j < 0 || (1 << j) >= c->world) return cfail(QSIM_ERR_ARG, "rank bit %d outside the world", j);
     const Roles ro = roles_of(c->rank, m, st);
+    // The plan says this rank holds nothing here; that is only true on a run from |0...0> (qsim_reset_shard, then the plan's
+    // steps in order).  A shard that was written since would silently lose its amplitudes: refuse.
+    if (ro.empty_before && !qsim_holds_nothing(c->shard))
+        return cfail(QSIM_ERR_ARG, "the plan's exchange assumes a run from |0...0> (this rank should hold nothing here and does): reset the shards, then run the plan's steps in order");
     const size_t blk_bytes = ((size_t)16 << m) >> k;
     if (hipSetDevice(c->device) != hipSuccess) return cfail(QSIM_ERR_DEVICE, "hipSetDevice failed");
     hipStream_t stream = (hipStream_t)qsim_stream(c->shard);
@@ -1346,7 +1361,7 @@ static int rank_exchange(qsim_rank_comm *c, const Step &st) {
 
 extern "C" int qsim_rank_comm_exchange(qsim_rank_comm *c, const int *shard_bits, const int *local_bits, int k) {
     if (!c || !shard_bits || !local_bits) return cfail(QSIM_ERR_ARG, "NULL argument");
-    if (k < 1 || k > 16) return cfail(QSIM_ERR_ARG, "exchange of %d qubits unsupported here", k);
+    if (k < 1 || k > kMaxRoleBits) return cfail(QSIM_ERR_ARG, "exchange of %d qubits unsupported here (at most %d)", k, kMaxRoleBits);
     Step st;
     st.exchange = true;
     st.J.assign(shard_bits, shard_bits + k);

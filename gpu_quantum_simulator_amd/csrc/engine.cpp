@@ -451,6 +451,10 @@ extern "C" int qsim_get_support(qsim_state *s, uint64_t *support, int *kind, dou
     return QSIM_OK;
 }
 
+// 1 when the state is the all-zero vector of a shard that holds nothing (qsim_reset_shard(s, 0), nothing written since): gates
+// queued on it change nothing, so the queue does not matter and nothing is flushed.
+extern "C" int qsim_holds_nothing(const qsim_state *s) { return s && s->zero_ket_pending && s->zero_ket_amp == 0.0 ? 1 : 0; }
+
 // ---- gate queue ----------------------------------------------------------------------------------------
 static int enqueue(qsim_state *s, const QueuedGate &g) {
     s->queue.push_back(g);
@@ -1321,10 +1325,22 @@ extern "C" int qsim_pack_bits_sparse(qsim_state *s, const int *bits, int nbits, 
 extern "C" int qsim_flush_pack(qsim_state *s, const int *bits, int nbits, const int *to_bits, uint64_t konst, void *out, uint64_t needed, uint32_t skip_blocks,
                                void **packed_at, int *fused) {
     if (!s || !bits) return fail(QSIM_ERR_ARG, "NULL argument");
-    if (nbits < 1 || nbits > 3 || nbits > s->n) return fail(QSIM_ERR_ARG, "flush_pack: %d bits unsupported", nbits);
+    if (nbits < 1 || nbits > 8 || nbits > s->n) return fail(QSIM_ERR_ARG, "flush_pack: %d bits unsupported", nbits);
     for (int j = 0; j < nbits; j++)
         if (bits[j] < 0 || bits[j] >= s->n || (j && bits[j] <= bits[j - 1])) return fail(QSIM_ERR_ARG, "flush_pack: bit positions must be ascending and inside the shard");
-    if (s->f32) return fail(QSIM_ERR_ARG, "flush_pack: fp64 states only");
+    if (nbits > 3 || s->f32) {
+        // What a tile pass cannot re-lay-out (PackMap carries three selected bits, fp64): exchanges of 4..8 qubits — groups of 16
+        // and more shards — and fp32 states take the plain route, flush then the pack kernel, with the same sparse roles (blocks
+        // nobody reads are left out while the mask has a bit for each: k <= 5).  Only the one-buffer layout exists there.
+        if (to_bits || konst) return fail(QSIM_ERR_ARG, "flush_pack: %d bits%s only into one buffer (no to_bits / konst)", nbits, s->f32 ? " of an fp32 state" : "");
+        void *dst = out ? out : s->spare;
+        if (!dst) return fail(QSIM_ERR_ARG, "flush_pack: no output buffer (lend one with qsim_set_spare_buffer)");
+        const int rc = pack_common(s, bits, nbits, dst, nullptr, true, nbits <= 5 ? skip_blocks : 0);
+        if (rc) return rc;
+        if (packed_at) *packed_at = dst;
+        if (fused) *fused = 0;
+        return QSIM_OK;
+    }
     PackJob job;
     job.out = out;
     job.skip = skip_blocks;
@@ -1513,7 +1529,14 @@ static void set_sched_hint(uint64_t key, const SchedHint &now, bool is_default, 
     const SchedHint before = it == g_sched_hints.end() ? dflt : it->second;
     if (is_default) g_sched_hints.erase(key);
     else {
-        if (g_sched_hints.size() >= kMaxSchedHints && it == g_sched_hints.end()) g_sched_hints.clear();
+        if (g_sched_hints.size() >= kMaxSchedHints && it == g_sched_hints.end()) { // full: both tables start over together — a measured
+            g_sched_hints.clear();                                                // entry without its hint would pin a schedule nobody runs
+            const auto mine = g_sched_measured.find(key);
+            const bool keep = mine != g_sched_measured.end();
+            const RankedVariant kept = keep ? mine->second : RankedVariant{};
+            g_sched_measured.clear();
+            if (keep) g_sched_measured[key] = kept;
+        }
         g_sched_hints[key] = now;
     }
     if (before.commute != now.commute || before.cheap_margin != now.cheap_margin || before.lookahead != now.lookahead || before.cap != now.cap || before.seed != now.seed)
@@ -1545,6 +1568,28 @@ static void choose_schedule(qsim_state *s, const qsim_circuit *c, const SchedCon
     }
     const std::vector<QueuedGate> q = queue_of(c);
     const uint64_t key = gates_key(s, plan_identity(s, q.size(), scfg.initial_support), q.data(), q.size());
+    if (key_out) *key_out = key;
+    {
+        // A circuit whose schedule was chosen by measurement keeps it: no candidate is scheduled again (80 schedules cost about a
+        // second at n = 30), and the hint is put back in case the hint table was emptied in between (kMaxSchedHints) — without
+        // it the circuit would silently run its default schedule with the geometries measured for another one.
+        bool measured = false;
+        RankedVariant kept{};
+        {
+            std::lock_guard<std::mutex> lock(g_hints_mu);
+            auto it = g_sched_measured.find(key);
+            if (it != g_sched_measured.end()) { measured = true; kept = it->second; }
+        }
+        if (measured) {
+            set_sched_hint(key, kept.hint, kept.is_default, scfg);
+            Scheduler sv(with_hint(scfg, kept.hint));
+            feed(sv, c);
+            sv.finish(passes);
+            if (ranked) ranked->clear(); // nothing left to try
+            if (out) *out = std::move(passes);
+            return;
+        }
+    }
     // the variants: how many clusters a pass may take (where the engine sets a cap of its own: states of 4 GiB and more),
     // clusters may / may not overtake (commute), how eagerly passes inside the support are kept (cheap_margin), one more
     // pass of lookahead where the local search is on; the default comes first and wins ties
@@ -1588,25 +1633,6 @@ static void choose_schedule(qsim_state *s, const qsim_circuit *c, const SchedCon
                 variants.push_back(h);
                 try_variant(variants.size() - 1);
             }
-    }
-    if (key_out) *key_out = key;
-    {
-        bool measured = false;
-        RankedVariant kept{};
-        {
-            std::lock_guard<std::mutex> lock(g_hints_mu);
-            auto it = g_sched_measured.find(key);
-            if (it != g_sched_measured.end()) { measured = true; kept = it->second; }
-        }
-        if (measured) { // keep the measured choice; hand back ITS passes
-            Scheduler sv(with_hint(scfg, kept.hint));
-            feed(sv, c);
-            passes.clear();
-            sv.finish(passes);
-            if (ranked) ranked->clear(); // nothing left to try
-            if (out) *out = std::move(passes);
-            return;
-        }
     }
     set_sched_hint(key, variants[best], best == 0, scfg);
     if (out) *out = std::move(passes);

@@ -235,6 +235,9 @@ int qsim_swap_buffer(qsim_state *s, void **buffer_device);
  * qsim_state_buffer: the amplitude buffer as is — nothing launched, nothing written (for a caller about to overwrite it). */
 int qsim_set_support(qsim_state *s, uint64_t support);
 int qsim_get_support(qsim_state *s, uint64_t *support, int *kind, double *amp0);
+/* 1 when the state is the all-zero vector of a shard that holds nothing (qsim_reset_shard(s, 0), nothing written since); does
+ * not flush. */
+int qsim_holds_nothing(const qsim_state *s);
 int qsim_pack_bits_sparse(qsim_state *s, const int *bits, int nbits, void *dst_device, void *const *dst_blocks, uint32_t skip_blocks);
 void *qsim_state_buffer(qsim_state *s);
 /* qsim_flush and the re-layout of qsim_pack_bits_sparse in ONE call: when the last pass of the queue is a tile pass of the
@@ -244,7 +247,8 @@ void *qsim_state_buffer(qsim_state *s);
  * a shard-sized buffer), the other bits close ranks below, and konst is ORed into the index (a cluster that keeps every
  * shard's buffer in one allocation addresses "block b of member j" that way).  needed: source index bits that may be 1 where
  * the receivers expect data (a fusing pass over a partially written state only writes inside its support; if that does not
- * cover `needed` the pack kernel, which writes the zeros, is used).  Afterwards the state's own buffer holds stale data:
+ * cover `needed` the pack kernel, which writes the zeros, is used).  nbits = 4..8 (groups of 16 and more shards) and fp32
+ * states always take the pack kernel (*fused = 0) and only know the one-buffer layout (to_bits NULL, konst 0).  Afterwards the state's own buffer holds stale data:
  * hand it its new contents (receives, qsim_swap_buffer) and say what they are (qsim_set_support / qsim_reset_shard). */
 int qsim_flush_pack(qsim_state *s, const int *bits, int nbits, const int *to_bits, uint64_t konst, void *out_device, uint64_t needed,
                     uint32_t skip_blocks, void **packed_at, int *fused);
@@ -277,6 +281,8 @@ int qsim_cluster_num_shards(const qsim_cluster *c);
 qsim_state *qsim_cluster_shard(qsim_cluster *c, int shard);
 int qsim_cluster_set_option(qsim_cluster *c, int option, long value);
 int qsim_cluster_reset(qsim_cluster *c); /* |0...0>, identity qubit map */
+/* ONE circuit per reset (compute_state_vector semantics): the plan's free first qubit placement and its sparse exchanges are
+ * only right from |0...0>, so a call that does not follow qsim_cluster_reset fails with QSIM_ERR_ARG instead of dropping data. */
 int qsim_cluster_run_circuit(qsim_cluster *c, const qsim_circuit *circuit);
 int qsim_cluster_sync(qsim_cluster *c);
 /* Planning for a circuit the cluster will run (repeatedly): the shard plan is built and kept, and every shard's local steps go
@@ -357,6 +363,8 @@ int qsim_rank_comm_exchange(qsim_rank_comm *c, const int *shard_bits, const int 
 /* The exchange of step `step` of a plan, using what the plan knows about the state there (qsim_shard_plan_step_support): ranks
  * that hold nothing do not pack or send, blocks that are zero throughout are not received, and the shard's engine is told
  * where its new contents can be non-zero (qsim_set_support) or that it holds nothing (qsim_reset_shard). */
+/* A plan's steps are only right in order from qsim_reset_shard (|0...0>): a rank the plan takes to hold nothing and that does hold
+ * something is refused (QSIM_ERR_ARG).  Exchanges swap at most 5 qubits (groups of 32 ranks). */
 int qsim_rank_comm_exchange_step(qsim_rank_comm *c, const qsim_shard_plan *p, int step);
 int qsim_rank_comm_stats(qsim_rank_comm *c, uint64_t *exchanges, double *bytes_sent, double *seconds, int reset);
 int qsim_rank_comm_pack_counts(const qsim_rank_comm *c, uint64_t *fused, uint64_t *separate); /* as qsim_cluster_pack_counts */

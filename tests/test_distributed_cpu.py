@@ -347,10 +347,12 @@ def _pack_np(state, m, Lsel):
     return state[src]
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("world", [2, 4, 8, 16, 32])
 @pytest.mark.parametrize("n,depth,seed,vocab", [(7, 120, 21, "all"), (10, 400, 22, "all"), (12, 500, 23, "clifford_t"), (11, 60, 24, "all"),
                                                 (15, 260, 25, "all"), (15, 120, 26, "clifford_t"), (16, 88, 9424, "all")])  # shards of >= 2^12: the hand-over is active
 def test_sparse_exchange_protocol_on_poisoned_memory(oracle, tmp_path, world, n, depth, seed, vocab):
+    if world >= 16 and n < 10:
+        pytest.skip("shards of fewer than 2^5 amplitudes")
     """What an exchange may leave out (csrc/dist.cpp roles_of; qsim_shard_plan_exchange_roles): shards that hold nothing
     neither pack nor send, blocks that are zero throughout are not received, and a receiver only ever looks inside its
     new support.  Modelled here with numpy shards whose memory is NaN wherever the protocol did not write: if a block that
@@ -388,6 +390,9 @@ def test_sparse_exchange_protocol_on_poisoned_memory(oracle, tmp_path, world, n,
             continue
         _, J, Lsel = st
         k = len(J)
+        # widths the executing paths accept: a tile pass re-lays out <= 3 bits, qsim_flush_pack falls back to the pack
+        # kernel up to 8, and the role masks (uint32, one bit per block) bound an exchange at 5 qubits = groups of 32 shards
+        assert 1 <= k <= 5 and k <= p and len(set(J)) == k and len(set(Lsel)) == k and all(0 <= b < m for b in Lsel)
         blk = 1 << (m - k)
         roles = [h.exchange_roles(i, r) for r in range(world)]
         mixed_local, mixed_rank = h.step_support(i)

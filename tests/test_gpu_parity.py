@@ -227,7 +227,7 @@ def test_full_size_two_paths_agree(n, vocab):
     assert np.max(np.abs(fused - plain)) < TOL
 
 
-@pytest.mark.parametrize("shards", [2, 8])
+@pytest.mark.parametrize("shards", [2, 4, 8])
 def test_full_size_sharded_run_agrees_with_the_single_state(shards):
     """BASELINE configs[3] as it is asked for on 2 / 4 / 8 GPUs — `random circuit n=30, depth 1000`, bench.py's seed — through the
     sharded path at full size: P shards on this one device (the links taken out, everything else as on P devices: the planner's
@@ -250,6 +250,39 @@ def test_full_size_sharded_run_agrees_with_the_single_state(shards):
         assert ex >= 2 and fused > 0 and separate == 0  # really sharded, and no re-layout needed a sweep of its own
     assert np.max(np.abs(single)) > 1e-6
     assert np.max(np.abs(sharded - single)) < TOL
+
+
+def test_largest_sharded_config_on_virtual_shards():
+    """BASELINE configs[4] — `n=33 fp64 (128 GiB state) across 8 GPUs`, cross-GPU 2-qubit gates straddling the shard boundary —
+    through the sharded path at FULL size on this one device: 8 virtual shards of 16 GiB (one 128 GiB state pool + one 128 GiB
+    scratch pool; the links taken out, everything else as on 8 devices: planner, support through the exchanges, every
+    re-layout on the last tile pass, per-shard schedules) against the single state's fuse-3 run of the same circuit
+    (`random circuit (all), n=33, depth 1000`, seed 20240150 = bench.py's), ~20 000 sampled amplitudes in LOGICAL order within
+    1e-10, both norms 1.  Two times 128 GiB plus a third 128 GiB do not fit one card, so the single state runs first (in place),
+    only its samples are kept, then the cluster.  If the card cannot hold the two pools the same check runs at n=32 / P=8 and says
+    so (pytest -rs shows the reason in the skip-less form: the assertion message names the size that ran).
+    The relabelling idea the planner inverts: quantum_simulator_4x4_permute.cu:377-434."""
+    import torch
+    from gpu_quantum_simulator_amd import Cluster
+    free_b, total_b = torch.cuda.mem_get_info()
+    n = 33 if free_b > 2 * (16 << 33) + total_b // 32 else 32
+    shards = 8
+    c = Circuit.from_gates(n, circuits.random_gates(n, 1000, 20240117 + n, "all"))
+    with Simulator(n, fuse=3, pingpong=0) as sim:
+        sim.run(c)
+        assert abs(sim.norm2() - 1.0) < 1e-10
+        single = _sample_windows(sim, n, 7)
+    with Cluster(n, shards, devices=[0] * shards) as cl:
+        cl.plan(c)
+        cl.run(c)
+        assert abs(cl.norm2() - 1.0) < 1e-10
+        sharded = _sample_windows(cl, n, 7)
+        ex, _ = cl.exchange_stats()
+        fused, separate = cl.pack_counts()
+        assert ex >= 2 and fused > 0 and separate == 0, (n, ex, fused, separate)
+    assert np.max(np.abs(single)) > 1e-7, n
+    assert np.max(np.abs(sharded - single)) < TOL, n
+    print(f"configs[4] on virtual shards ran at n={n}, P={shards}: {ex} exchanges, re-layouts fused/separate = {fused}/{separate}")
 
 
 @pytest.mark.parametrize("n", [32, 33])
@@ -1421,3 +1454,69 @@ def test_flush_pack_on_partial_states_and_fallbacks(oracle, tmp_path):
         sim.sync()
         assert not fused
         assert np.max(np.abs(out.cpu().numpy().reshape(-1).view(np.complex128) - w2[_pack_src_index(n2, (2, 7))])) < TOL
+
+
+@pytest.mark.parametrize("bits", [(1, 5, 9, 13), (0, 3, 4, 11, 14)])
+def test_flush_pack_of_wide_exchanges_takes_the_pack_kernel(oracle, tmp_path, bits):
+    """Exchanges of 4 and 5 qubits — groups of 16 and 32 shards, what the planner emits for P = 16 / 32 — go through the same call
+    as the narrow ones (exchange_rccl, rank_exchange: qsim_flush_pack into the scratch buffer).  A tile pass re-lays out at most
+    three bits, so these take flush + the pack kernel inside that call, with the sparse roles kept: same amplitudes in the same
+    places as the index permutation says, blocks in `skip_blocks` untouched, and the steered forms (to_bits / konst) refused
+    rather than mis-executed (the call used to fail with "4 bits unsupported" on every 16-rank run)."""
+    import torch
+    n = 15
+    gates = circuits.random_gates(n, 300, 177, "all")
+    path = circuits.write_qasm(str(tmp_path / "w.qasm"), n, gates)
+    _, want, _, _ = oracle.run_qasm(path)
+    c = Circuit.from_file(path)
+    src = _pack_src_index(n, bits)
+    k = len(bits)
+    blk = 1 << (n - k)
+    with Simulator(n, fuse=3) as sim:
+        out = torch.full((1 << n, 2), float("nan"), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        sim.run(c)
+        at, fused = sim.flush_pack(bits, out.data_ptr())
+        sim.sync()
+        assert not fused and at == out.data_ptr()
+        got = out.cpu().numpy().reshape(-1).view(np.complex128)
+        assert np.max(np.abs(got - want[src])) < TOL
+        skip = 0b1010010010 & ((1 << (1 << k)) - 1)
+        out.fill_(float("nan")); torch.cuda.synchronize()
+        sim.reset(); sim.run(c)
+        at, fused = sim.flush_pack(bits, out.data_ptr(), skip_blocks=skip)
+        sim.sync()
+        got = out.cpu().numpy().reshape(-1).view(np.complex128)
+        for b in range(1 << k):
+            piece = got[b * blk:(b + 1) * blk]
+            if skip >> b & 1:
+                assert np.isnan(piece).all(), b
+            else:
+                assert np.max(np.abs(piece - want[src][b * blk:(b + 1) * blk])) < TOL, b
+        with pytest.raises(_lib.QsimError):
+            sim.flush_pack(bits, out.data_ptr(), to_bits=[n - k + j for j in range(k)], konst=1 << n)
+
+
+def test_cluster_runs_one_circuit_per_reset(oracle, tmp_path):
+    """qsim_cluster_run_circuit is compute_state_vector's contract (quantum_simulator.c:115-254): one circuit, from |0...0>.  The plan
+    relies on it (free first placement, exchanges that leave out what is still zero), so a second circuit without a reset in
+    between is refused — it used to run and, after a circuit whose qubit map ended as the identity, silently dropped amplitudes
+    (ADVICE r03).  With the reset both runs give the oracle's amplitudes."""
+    from gpu_quantum_simulator_amd import Cluster
+    n = 14
+    lib = _lib.load()
+    first = circuits.write_qasm(str(tmp_path / "a.qasm"), n, [("h", 0), ("cx", 0, 1), ("t", 1)])  # no exchange: the map stays the identity
+    second = circuits.write_qasm(str(tmp_path / "b.qasm"), n, circuits.random_gates(n, 200, 31, "all"))
+    ca, cb = Circuit.from_file(first), Circuit.from_file(second)
+    with Cluster(n, 4, devices=[0] * 4) as cl:
+        assert lib.qsim_cluster_run_circuit(cl._h, ca._h) != 0  # a fresh cluster has not been reset either
+        assert b"reset" in lib.qsim_cluster_error()
+        cl.run(ca)  # reset + run
+        _, want, _, _ = oracle.run_qasm(first)
+        assert np.max(np.abs(cl.read() - want)) < TOL
+        assert lib.qsim_cluster_run_circuit(cl._h, cb._h) != 0
+        assert b"reset" in lib.qsim_cluster_error()
+        assert np.max(np.abs(cl.read() - want)) < TOL  # the refused call touched nothing
+        cl.run(cb)
+        _, want, _, _ = oracle.run_qasm(second)
+        assert np.max(np.abs(cl.read() - want)) < TOL

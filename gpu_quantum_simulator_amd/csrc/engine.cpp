@@ -513,12 +513,13 @@ static inline int local_bit(const TileGeom &g, int q) {
 }
 
 // TileBlock -> device TileOp.  Returns false when a qubit is on the wrong side of the tile or the block cannot be
-// expressed (Scheduler::merge_blocks never produces such a block).
-static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, int amp_shift = 4) {
+// expressed (Scheduler::merge_blocks never produces such a block).  f32: the state holds fp32 amplitudes — 8-byte LDS slots,
+// coefficients rounded once, here, and stored as the float pairs the fp32 kernels consume (kernels_impl.inc coef_t).
+static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, bool f32 = false) {
     memset(&t, 0, sizeof t);
-    const int k = blk.nq, D = blk.dim(), NB = blk.banks();
+    const int amp_shift = f32 ? 3 : 4;
+    const int k = blk.nq, NB = blk.banks();
     if (k > kMaxOpQ || blk.ns > 2) return false;
-    t.nq = k;
     t.nsel = blk.ns;
     for (int a = 0; a < blk.ns; a++) {
         if (local_bit(g, blk.s[a]) >= 0 || blk.s[a] < 0 || blk.s[a] >= g.n) return false; // selectors lie outside the tile
@@ -527,77 +528,136 @@ static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, int a
     // qbit[a]: tile-local bit of the block's a-th qubit in ascending GLOBAL order = bit a of a row / column index.
     // t.b[]: the same bits sorted ascending — what the kernel inserts zeros at to enumerate the block's groups.  The two
     // orders agree while TileGeom::high is ascending and differ once the engine reorders the tile bits.
-    int qbit[kMaxOpQ] = {0, 0, 0, 0, 0};
+    int qbit[kMaxOpQ] = {0, 0, 0, 0, 0, 0};
+    uint32_t used = 0;
     for (int a = 0; a < k; a++) {
         const int lb = local_bit(g, blk.q[k - 1 - a]);
         if (lb < 0) return false;
         qbit[a] = lb;
-        t.b[a] = lb;
+        used |= 1u << lb;
     }
-    std::sort(t.b, t.b + k);
     auto is1 = [&](const cd &z) { return z.real() == 1.0 && z.imag() == 0.0; };
-    auto put = [&](int v, int e, const cd &z) { t.re[v][e] = z.real(); t.im[v][e] = z.imag(); };
+    // a coefficient in the form the kernels read it: fp64 (re, im); fp32 the pairs (ur, ui), (-ui, ur) in the same 16 bytes
+    auto put = [&](double *slot, const cd &z) {
+        if (!f32) { slot[0] = z.real(); slot[1] = z.imag(); return; }
+        const float r = (float)z.real(), i = (float)z.imag();
+        const float four[4] = {r, i, -i, r};
+        memcpy(slot, four, sizeof four);
+    };
     for (int v = 0; v < NB; v++)
         if (blk.bank_is_identity(v)) t.ident |= 1 << v;
     if (k == 0) { // tile-uniform factor
         if (blk.ns == 0) return false;
         t.kind = TOP_SCALE;
-        for (int v = 0; v < NB; v++) put(v, 0, blk.at(v, 0, 0));
-        return true;
-    }
-    const int maxnnz = blk.max_row_nnz();
-    if (k == 1) {
-        bool diag = true;
-        for (int v = 0; v < NB; v++) diag = diag && blk.at(v, 0, 1) == cd(0, 0) && blk.at(v, 1, 0) == cd(0, 0);
-        t.kind = diag ? TOP_DIAG1 : TOP_G1;
         for (int v = 0; v < NB; v++) {
-            if (diag) {
-                put(v, 0, blk.at(v, 0, 0));
-                put(v, 1, blk.at(v, 1, 1));
-                t.meta[v] = is1(blk.at(v, 0, 0)) ? 1 : 0;
-            } else {
-                for (int e = 0; e < 4; e++) put(v, e, blk.at(v, e >> 1, e & 1));
-            }
+            const cd z = blk.at(v, 0, 0);
+            if (f32) { const float two[2] = {(float)z.real(), (float)z.imag()}; memcpy(t.scale[v], two, sizeof two); }
+            else { t.scale[v][0] = z.real(); t.scale[v][1] = z.imag(); }
         }
         return true;
     }
-    if (k == 2 && maxnnz > 2) { // dense 4x4: register form
+    const int maxnnz = blk.max_row_nnz();
+    if (maxnnz > 4) return false;
+    if (g.tile_bits < 3) { // a register of one or two qubits: no three tile bits to pad a block to, the pair / quad forms stay
+        for (int a = 0; a < k; a++) t.b[a] = (uint8_t)qbit[a];
+        std::sort(t.b, t.b + k);
+        t.nq = k;
+        if (k == 1) {
+            bool diag = true;
+            for (int v = 0; v < NB; v++) diag = diag && blk.at(v, 0, 1) == cd(0, 0) && blk.at(v, 1, 0) == cd(0, 0);
+            t.kind = diag ? TOP_DIAG1 : TOP_G1;
+            for (int v = 0; v < NB; v++) {
+                if (diag) {
+                    put(&t.rec[v][0].coef[0], blk.at(v, 0, 0));
+                    put(&t.rec[v][0].coef[2], blk.at(v, 1, 1));
+                    t.rec[v][0].off[0] = is1(blk.at(v, 0, 0)) ? 1 : 0;
+                } else {
+                    for (int e = 0; e < 4; e++) put(&t.rec[v][0].coef[2 * e], blk.at(v, e >> 1, e & 1));
+                }
+            }
+            return true;
+        }
+        if (k != 2) return false;
         t.kind = TOP_G2; // the kernel's index bit 0 is t.b[0], bit 1 is t.b[1]: swap the qubits' roles if the tile order did
         const bool swapped = qbit[0] > qbit[1];
         auto sw = [&](int i) { return swapped ? ((i & 1) << 1) | (i >> 1) : i; };
         for (int v = 0; v < NB; v++)
-            for (int e = 0; e < 16; e++) put(v, e, blk.at(v, sw(e >> 2), sw(e & 3)));
+            for (int e = 0; e < 16; e++) put(&t.rec[v][0].coef[2 * e], blk.at(v, sw(e >> 2), sw(e & 3)));
         return true;
     }
-    if (maxnnz > 4) return false;
     // rows laid out class by class (TileBlock::classes): T rows that read the same T operand slots
     int T = 1;
     std::vector<std::vector<int>> crows, ccols;
-    if (!blk.classes(T, crows, ccols)) return false;
-    t.kind = TOP_SP;
+    if (k == 1) { // classes() speaks about blocks on two and more qubits; a 2x2 is one class of two rows, or two of one
+        bool diag = true;
+        for (int v = 0; v < NB; v++) diag = diag && blk.at(v, 0, 1) == cd(0, 0) && blk.at(v, 1, 0) == cd(0, 0);
+        T = diag ? 1 : 2;
+        crows.assign((size_t)NB, {0, 1});
+        ccols.assign((size_t)NB, {0, 1});
+    } else if (!blk.classes(T, crows, ccols)) return false;
+    // Fewer than three qubits: pad with tile bits the block does not touch (it acts on them as the identity).  Same LDS
+    // reads, multiply-adds and writes per amplitude as the pair / quad forms had, through the one code path of the part form.
+    int K = k;
+    for (int lb = 0; K < 3 && lb < g.tile_bits; lb++)
+        if (!(used >> lb & 1u)) { qbit[K++] = lb; used |= 1u << lb; }
+    if (K < 3) return false;
+    const int pad = K - k, D = 1 << k, DK = 1 << K;
+    t.kind = TOP_PART;
+    t.nq = K;
     t.terms = T;
-    // LDS BYTE offset of a slot code (bit a of the code sits at tile-local bit b[a]), already passed through the
+    for (int a = 0; a < K; a++) t.b[a] = (uint8_t)qbit[a];
+    std::sort(t.b, t.b + K);
+    for (int a = K; a < 8; a++) t.b[a] = 31; // the kernel inserts a zero at every entry: at bit 31 that is a no-op
+    // LDS BYTE offset of a slot code (bit a of the code sits at tile-local bit qbit[a]), already passed through the
     // kernel's layout swizzle (kernels_impl.inc sw_slot: unit bits 0..3 ^= a linear image of the higher slot bits;
     // linear, so it commutes with the XOR the kernel combines it with)
     auto slot_off = [&](int code) {
         uint32_t o = 0;
-        for (int a = 0; a < k; a++) o |= (uint32_t)((code >> a) & 1) << qbit[a];
+        for (int a = 0; a < K; a++) o |= (uint32_t)((code >> a) & 1) << qbit[a];
         const uint32_t hi = o >> 4, f = (hi ^ (hi >> 5) ^ (hi >> 10)) & 31u; // = sw_fold of kernels_impl.inc
-        if (amp_shift == 3) return o ^ ((0u - (hi & 1u)) & 15u);            // fp32 states keep the bit-4-only swizzle
-        return o ^ (((f >> 1) & 15u) ^ ((0u - (f & 1u)) & 15u));
+        if (f32) return (o ^ ((0u - (hi & 1u)) & 15u)) << amp_shift;         // fp32 states keep the bit-4-only swizzle
+        return (o ^ (((f >> 1) & 15u) ^ ((0u - (f & 1u)) & 15u))) << amp_shift;
     };
+    bool closed = true, skips = false;
     for (int v = 0; v < NB; v++)
-        for (int p = 0; p < D; p++) { // position p = row crows[v][p]; its class reads the columns ccols[v][cT .. cT+T)
-            const int r = crows[v][p], c0 = (p / T) * T;
-            const TileBlock::Row &row = blk.row(v, r);
-            t.rowoff[v][p] = slot_off(r) << amp_shift;
+        for (int p = 0; p < DK; p++) { // position p = copy (p / D) of the block over the padding bits, row crows[v][p % D] of it
+            const int hi = (p / D) << k, r0 = crows[v][(size_t)(p % D)], r = hi | r0, c0 = ((p % D) / T) * T;
+            PartRec &rec = t.rec[v][p / kPartRows];
+            const int pp = p % kPartRows, cc = (pp / T) * T;
+            rec.rowoff[pp] = slot_off(r);
             for (int j = 0; j < T; j++) {
-                const int col = ccols[v][c0 + j];
-                t.off[v][c0 + j] = slot_off(col) << amp_shift; // the same list from every row of the class
-                put(v, p * T + j, blk.at(v, r, col)); // exact zero where the row does not use the column
+                const int col = ccols[v][(size_t)(c0 + j)];
+                rec.off[cc + j] = slot_off(hi | col); // the same list from every row of the class
+                put(&rec.coef[(size_t)(pp * T + j) * 2], blk.at(v, r0, col)); // exact zero where the row does not use the column
             }
-            if (row.n == 1 && row.col[0] == r && is1(row.val[0])) t.meta[v] |= 1u << p; // identity row
         }
+    (void)pad;
+    for (int v = 0; v < NB; v++)
+        for (int part = 0; part < DK / kPartRows; part++) {
+            PartRec &rec = t.rec[v][part];
+            uint64_t reads = 0, writes = 0; // slot codes are < 64: compare the part's operand slots with the slots it writes
+            for (int pp = 0; pp < kPartRows; pp++) {
+                const int p = part * kPartRows + pp, hi = (p / D) << k;
+                writes |= 1ULL << (hi | crows[v][(size_t)(p % D)]);
+                reads |= 1ULL << (hi | ccols[v][(size_t)(p % D)]);
+            }
+            if (reads != writes) closed = false;
+            for (int c = 0; c < kPartRows / T; c++) { // a class of identity rows only: nothing to do
+                bool ident = true;
+                for (int i = 0; i < T && ident; i++) {
+                    const int p = part * kPartRows + c * T + i, r0 = crows[v][(size_t)(p % D)];
+                    const TileBlock::Row &row = blk.row(v, r0);
+                    ident = row.n == 1 && row.col[0] == r0 && is1(row.val[0]);
+                }
+                if (ident) { // the kernel asks off[] before its reads and rowoff[] before its writes
+                    rec.off[c * T] = kSkipClass;
+                    for (int i = 0; i < T; i++) rec.rowoff[c * T + i] = kSkipClass;
+                    skips = true;
+                }
+            }
+        }
+    if (skips) t.flags |= kOpFlagSkips;
+    if (closed) t.flags |= kOpFlagClosed;
     return true;
 }
 
@@ -723,16 +783,7 @@ static int launch_tile_pass(qsim_state *s, const Pass &p, const TileGeom &geom, 
     }
     TileOp *h = s->h_ops + s->ops_used;
     for (size_t k = 0; k < need; k++)
-        if (!to_tile_op(geom, p.blocks[k], h[k], s->f32 ? 3 : 4)) return fail(QSIM_ERR_ARG, "internal: block does not fit its tile pass");
-    if (s->f32) // the fp32 kernels read every coefficient as two float pairs, (ur, ui) in its re[] slot and (-ui, ur) in its im[] slot
-        for (size_t k = 0; k < need; k++)     // (kernels_impl.inc coef_t: v_pk_fma_f32 operands straight from scalar loads); rounded once, here
-            for (int v = 0; v < kMaxBanks; v++)
-                for (int e = 0; e < kMaxOpEntries; e++) {
-                    const float r = (float)h[k].re[v][e], i = (float)h[k].im[v][e];
-                    const float a[2] = {r, i}, b[2] = {-i, r};
-                    memcpy(&h[k].re[v][e], a, sizeof a);
-                    memcpy(&h[k].im[v][e], b, sizeof b);
-                }
+        if (!to_tile_op(geom, p.blocks[k], h[k], s->f32)) return fail(QSIM_ERR_ARG, "internal: block does not fit its tile pass");
     if (capture) capture->insert(capture->end(), h, h + need);
     TileOp *d = s->d_ops + s->ops_used;
     HIP_TRY(hipMemcpyAsync(d, h, need * sizeof(TileOp), hipMemcpyHostToDevice, s->stream));
@@ -1990,8 +2041,8 @@ extern "C" int qsim_schedule_circuit(const qsim_circuit *c, int fuse, int tile_b
     std::vector<Pass> passes;
     sched.finish(passes);
     int pi = 0;
-    std::vector<double> big((size_t)2 * 128 * 128);
-    std::vector<cd> full((size_t)128 * 128);
+    std::vector<double> big((size_t)2 * 256 * 256);
+    std::vector<cd> full((size_t)256 * 256);
     for (const Pass &p : passes) {
         for (const FusedOp &op : p.ops) {
             double U[128];
@@ -2007,10 +2058,10 @@ extern "C" int qsim_schedule_circuit(const qsim_circuit *c, int fuse, int tile_b
             const int nq = blk.ns + blk.nq, D = 1 << nq;
             blk.full_matrix(full.data());
             for (int k = 0; k < D * D; k++) { big[2 * k] = full[k].real(); big[2 * k + 1] = full[k].imag(); }
-            int qs[7], j = 0;
+            int qs[kMaxBlockQ + 2], j = 0;
             for (int a = 0; a < blk.ns; a++) qs[j++] = blk.s[a];
             for (int a = 0; a < blk.nq; a++) qs[j++] = blk.q[a];
-            static const int kinds[8] = {0, QSIM_GATE_U1, QSIM_GATE_U2, QSIM_GATE_U3, QSIM_GATE_U4, QSIM_GATE_U5, QSIM_GATE_U6, QSIM_GATE_U7};
+            static const int kinds[9] = {0, QSIM_GATE_U1, QSIM_GATE_U2, QSIM_GATE_U3, QSIM_GATE_U4, QSIM_GATE_U5, QSIM_GATE_U6, QSIM_GATE_U7, QSIM_GATE_U8};
             cb(user, pi, p.kclass, kinds[nq], qs, nq, big.data(), (int)blk.gates);
         }
         pi++;

@@ -14,58 +14,64 @@ namespace qsim {
 struct M2 { double re[4], im[4]; };
 struct M4 { double re[16], im[16]; };
 
-// One fused block inside a cache-blocked pass.  Bit positions are TILE-LOCAL (see TileGeom), ascending:
-// b[0] is the block's lowest qubit = bit 0 of a slot code, b[k-1] its highest = the slot code's top bit.
-//   TOP_G1     dense 2x2 on b[0]                      re/im[bank][0..3] row-major
-//   TOP_DIAG1  diag(d0, d1) on b[0]                   re/im[bank][0..1]; meta[bank] bit 0: d0 == 1 (only the bit=1 half moves)
-//   TOP_G2     dense 4x4 on (b[1], b[0])              re/im[bank][0..15] row-major, operands held in registers
-//   TOP_SP     sparse 2^k x 2^k block, k = nq in {2..5}, `terms` = T (1, 2 or 4) entries per row.  Per bank the block is a
-//              direct sum of small dense matrices in a permuted basis (Scheduler / TileBlock::classes), so its rows are
-//              stored CLASS by class: positions cT .. cT+T-1 are T rows that read the same T operand slots.  A class
-//              costs T LDS reads for T outputs — ONE read per amplitude whatever T is (the first version read every
-//              row's operands separately: T reads per amplitude; the block phase of a pass is LDS-bound, so that
-//              was a third of its time):
-//                  x[j] = slot off[bank][cT + j]               (one operand list per class)
-//                  y[cT+i] = sum_j coef[bank][(cT+i)*T + j] * x[j]     -> written to slot rowoff[bank][cT+i]
-//              Offsets are ready LDS byte offsets (wave-uniform, layout swizzle applied).  meta[bank] bit p: position p is
-//              an identity row; a class whose T rows all are costs nothing (identity rows are packed together).
-//              Most fused clusters of Clifford+T-like circuits are permutations times phases or two independent
-//              2x2 blocks, and so are products of neighbouring ones on a few qubits (Scheduler::merge_blocks).
-//              k <= 3: one lane owns a whole group of 2^k amplitudes (reads, then writes).  k = 4, 5: the 2^k positions of a
-//              group are split over 2 or 4 lanes (8 positions = whole classes each, in different waves), with a workgroup
-//              barrier between everybody's reads and the writes.
-//   TOP_SCALE  no qubit inside the tile: a factor per tile, applied while the tile is staged in.
+// One fused block inside a cache-blocked pass = one trip of the tile through LDS.  Bit positions are TILE-LOCAL (see TileGeom),
+// ascending: b[0] is the block's lowest qubit = bit 0 of a slot code, b[k-1] its highest = the slot code's top bit.
+//
+//   TOP_PART   sparse 2^k x 2^k block on k = nq in {3..6} tile qubits, `terms` = T (1, 2 or 4) entries per row.  Per bank the
+//              block is a direct sum of small dense matrices in a permuted basis (Scheduler / TileBlock::classes), so its rows
+//              are laid out CLASS by class: T rows that read the same T operand slots — ONE LDS read per amplitude whatever T is.
+//              The 2^k positions of a group are dealt in PARTS of 8 (8 / T whole classes); a lane owns one (group, part), the
+//              parts of a group sit in different waves (part-major), so everything a wave needs of the block — operand offsets,
+//              row offsets, coefficients — is ONE wave-uniform record (PartRec) read through scalar loads at immediate offsets
+//              from one pointer:
+//                  x[j]      = slot rec.off[c*T + j]                           (class c of the part, j < T)
+//                  y[c*T+i]  = sum_j rec.coef[(c*T+i)*T + j] * x[j]            -> written to slot rec.rowoff[c*T+i]
+//              Offsets are ready LDS byte offsets (layout swizzle applied).  A class whose T rows are all identity rows costs
+//              nothing: off[c*T] = kSkipClass and rowoff[c*T .. c*T+T) = kSkipClass.  k > 3 needs a workgroup barrier between everybody's reads and the writes unless
+//              every part writes exactly the slots it read (flags bit 1).
+//              Blocks on fewer than three qubits are PADDED by the engine with tile bits they act on as the identity (same reads,
+//              same multiply-adds, same writes per amplitude; one code path, one dispatch).
+//              Most fused clusters of Clifford+T-like circuits are permutations times phases or two independent 2x2 blocks, and
+//              so are products of neighbouring ones on a few qubits (Scheduler::merge_blocks).
+//   TOP_SCALE  no qubit inside the tile: a factor per tile, applied while the tile is staged in (scale[bank]).
+//   TOP_G1 / TOP_DIAG1 / TOP_G2   dense 2x2 / diagonal / dense 4x4 in pair and quad form: only in tiles of fewer than 2^3
+//              amplitudes (registers of one or two qubits), which have no three bits to pad to; coefficients row-major in
+//              rec[bank][0].coef as (re, im); TOP_DIAG1: rec[bank][0].off[0] = 1 when d0 == 1 (only the bit = 1 half moves).
 // BANKS.  A block may also depend on up to two qubits OUTSIDE the tile, provided it is block-diagonal in them (a CX
 // whose control is outside, any diagonal gate): such a qubit is constant over a tile, so it merely selects which
 // 2^k x 2^k sub-block the tile gets.  nsel / selbit name those GLOBAL index bits; the bank index is
 // bit(selbit[0]) or 2*bit(selbit[0]) + bit(selbit[1]) of the tile's base index, wave-uniform, and only that bank's
-// offsets and coefficients are ever loaded.  `ident` bit v: bank v is the identity — the block is skipped on those tiles.
-// TOP_SCALE uses the same selection and reads its factor from re/im[bank][0].
-enum : int32_t { TOP_G1 = 1, TOP_G2 = 2, TOP_DIAG1 = 3, TOP_SP = 4, TOP_SCALE = 5 };
+// records are ever loaded.  `ident` bit v: bank v is the identity — the block is skipped on those tiles.
+enum : int32_t { TOP_G1 = 1, TOP_G2 = 2, TOP_DIAG1 = 3, TOP_PART = 4, TOP_SCALE = 5 };
 constexpr int kMaxBanks = 4;
-constexpr int kMaxOpQ = 5;                      // TOP_SP blocks span 2..5 tile qubits
-constexpr int kMaxOpEntries = 4 << kMaxOpQ;     // 4 entries for each of 32 rows
+constexpr int kMaxOpQ = 6;                      // TOP_PART blocks span 3..6 tile qubits
+constexpr int kPartRows = 8;                    // positions per part
+constexpr int kMaxParts = 1 << (kMaxOpQ - 3);
+constexpr uint32_t kSkipClass = 0xFFFFFFFFu;
+constexpr uint32_t kOpFlagSkips = 1u, kOpFlagClosed = 2u;
+struct PartRec {
+    uint32_t off[kPartRows];      // operand j of class c at [c*T + j]
+    uint32_t rowoff[kPartRows];   // position p writes slot rowoff[p]
+    double coef[kPartRows * 4 * 2]; // entry j of position p: (re, im) at [(p*T + j)*2]; fp32 states: the float pairs (ur, ui), (-ui, ur) in the same 16 bytes
+};
 struct TileOp {
-    // 64-byte header; the kernel fetches its first 32 bytes with ONE scalar load (s_load_dwordx8) and decodes them with
-    // scalar bit-field extracts, one block ahead of the block it is working on — read field by field, the dispatch was a
-    // chain of six dependent scalar-load round trips per block and wave (kind -> selectors -> bank -> identity -> shape ->
-    // tile bits) before the first LDS read could be issued.
+    // the first 16 bytes are fetched with ONE scalar load (s_load_dwordx4) a block ahead of their use and decoded with scalar
+    // bit-field extracts
     uint8_t kind;         // dword 0
-    uint8_t nq;           //   qubits of the block inside the tile (0..5)
-    uint8_t terms;        //   TOP_SP: T = rows per class = entries per row (1, 2, 4), the same for every bank
+    uint8_t nq;           //   qubits of the block inside the tile (TOP_PART: 3..6 after padding)
+    uint8_t terms;        //   TOP_PART: T = rows per class = entries per row (1, 2, 4), the same for every bank
     uint8_t nsel;         //   0..2 selecting qubits
     uint8_t selbit[2];    // dword 1: their global index bits, most significant bank bit first
     uint8_t ident;        //   bit v: bank v is the identity
-    uint8_t pad0;
+    uint8_t flags;        //   kOpFlagSkips: some class is skipped; kOpFlagClosed: no barrier between reads and writes
     uint8_t b[8];         // dwords 2-3: tile-local bits of the block's qubits, ascending (kMaxOpQ used)
-    uint32_t meta[kMaxBanks]; // dwords 4-7
+    uint32_t pad0[4];
+    double scale[kMaxBanks][2]; // TOP_SCALE: the factor per bank as (re, im); fp32 states: two floats in the first 8 bytes
     uint32_t pad1[8];
-    uint32_t rowoff[kMaxBanks][1 << kMaxOpQ]; // TOP_SP: LDS BYTE offset of the slot position p writes (class order differs per bank)
-    uint32_t off[kMaxBanks][1 << kMaxOpQ];    // TOP_SP: LDS BYTE offset of operand j of class c at [c*T + j] (one list per class)
-    double re[kMaxBanks][kMaxOpEntries];      // entry j of position p at [p*T + j]
-    double im[kMaxBanks][kMaxOpEntries];
+    PartRec rec[kMaxBanks][kMaxParts];
 };
-static_assert(sizeof(TileOp) == 64 + 4 * 128 + 4 * 128 + 8192 && offsetof(TileOp, meta) == 16 && offsetof(TileOp, rowoff) == 64, "TileOp layout is shared with the device");
+static_assert(sizeof(PartRec) == 64 + 512 && offsetof(TileOp, scale) == 32 && offsetof(TileOp, rec) == 128 &&
+              sizeof(TileOp) == 128 + kMaxBanks * kMaxParts * sizeof(PartRec), "TileOp layout is shared with the device");
 
 constexpr int kMaxTileHigh = 10; // high (non-contiguous) qubits per tile
 struct TileGeom {

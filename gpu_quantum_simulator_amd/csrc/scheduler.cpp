@@ -404,11 +404,11 @@ bool TileBlock::classes(int &T, std::vector<std::vector<int>> &rows, std::vector
 
 bool TileBlock::classes_feasible() const {
     const int D = dim(), NB = banks();
-    if (D > 32) return false;
+    if (D > 64) return false;
     int maxsz = 1;
     int cnt[kMaxBanks][kMaxRowNnz + 1]; // components by size, per bank
     for (int v = 0; v < NB; v++) {
-        unsigned char parent[64], nrow[64], ncol[64];
+        unsigned char parent[128], nrow[128], ncol[128];
         for (int i = 0; i < 2 * D; i++) { parent[i] = (unsigned char)i; nrow[i] = ncol[i] = 0; }
         auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
         for (int r = 0; r < D; r++)
@@ -948,10 +948,11 @@ int own_bank(const TileBlock &b, const int *ss, int nss, int v) {
 } // namespace
 
 void Scheduler::merge_blocks(std::vector<TileBlock> &blocks) const {
-    // Tiles of fewer than 2^11 amplitudes keep to 3 qubits: the forms for 4 and 5 split a group's rows over 2 or 4
-    // lanes' worth of waves and need 2^(B-5) >= 64 groups.
+    // Tiles of fewer than 2^11 amplitudes keep to 3 qubits: a block on k > 3 qubits deals the 2^(k-3) parts of a group to
+    // different waves, so a part must be at least one wave: 2^(B-k) >= 64 groups (k_tile's tile_op_part).  2^11 tiles take
+    // 5 qubits, 2^12 and larger 6.
     const int B = std::min(cfg_.tile_bits, cfg_.n);
-    const int kMaxQ = B >= 11 ? std::min(cfg_.merge_qubits, kMaxBlockQ) : 3;
+    const int kMaxQ = B >= 11 ? std::max(3, std::min(std::min(cfg_.merge_qubits, kMaxBlockQ), B - 6)) : 3;
     constexpr int kMaxSel = 2;
     std::vector<int> rem(blocks.size()), next; // indices into `blocks`: the blocks themselves are moved, never copied
     for (size_t i = 0; i < blocks.size(); i++) rem[i] = (int)i;

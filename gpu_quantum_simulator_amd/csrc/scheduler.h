@@ -48,10 +48,10 @@ struct FusedOp {
 // nq == 0: a tile-uniform factor (entry (0,0) of each bank).  Stored by rows, at most kMaxRowNnz entries each: that is
 // what one LDS trip of k_tile can evaluate (a dense 4x4 on two qubits is the fullest case), and it keeps the products
 // of merge_blocks cheap on up to kMaxBlockQ qubits.
-constexpr int kMaxBlockQ = 5, kMaxRowNnz = 4;
+constexpr int kMaxBlockQ = 6, kMaxRowNnz = 4;
 struct TileBlock {
     int nq = 0;
-    int q[kMaxBlockQ] = {-1, -1, -1, -1, -1}; // descending: q[0] is the most significant bit of the row/column index
+    int q[kMaxBlockQ] = {-1, -1, -1, -1, -1, -1}; // descending: q[0] is the most significant bit of the row/column index
     int ns = 0;
     int s[2] = {-1, -1};                      // descending: s[0] is the most significant bit of the bank index
     struct Row {
@@ -133,7 +133,7 @@ struct SchedConfig {
     int tail_max_ops = 0;  // > tile_max_ops: the cap of a pass that can take ALL remaining clusters (no straggler pass for a handful of gates)
     int window = 512;  // clusters scanned ahead when grouping a pass
     int merge = 1;     // level 3: merge neighbouring blocks of a pass into sparse blocks of up to merge_qubits tile qubits
-    int merge_qubits = 5;
+    int merge_qubits = 6; // round 4: 6 (64 rows = 8 parts of 8, one wave each in a 2^12 tile): 9 % fewer LDS trips than 5 at the same multiply-adds
     int rollout = 8;   // level 3: candidates tried (each by greedily finishing the pass) when a new qubit must be admitted; 0 = off
     int pad_from = 10; // first bit tried when unused tile slots are filled (below tile_low_bits: tile_low_bits)
     int lookahead = 0; // level 3: further passes (built greedily) whose reach is added to a candidate's score

@@ -110,7 +110,7 @@ class Circuit:
 
     def schedule(self, fuse: int = 3, tile_bits: int = 12, tile_low_bits: int = 3, tile_max_ops: int = 32) -> list:
         """Fused blocks in launch order: (pass, kernel_class, kind, qubits, matrix|None, gates_folded); kind is
-        "u1" / "cx" / "u2" / "u3", qubits most significant first (cx: control, target)."""
+        "u1" / "cx" / "u2" ... "u8", qubits most significant first (cx: control, target)."""
         out = []
 
         def cb(_user, pass_i, kclass, kind, qubits, nq, U, folded):
@@ -119,7 +119,7 @@ class Circuit:
             if kind != _lib.GATE_CX:
                 d = 1 << nq
                 m = np.ctypeslib.as_array(U, shape=(2 * d * d,)).copy().view(np.complex128).reshape(d, d)
-            out.append((pass_i, _lib.K_NAMES[kclass], {1: "u1", 2: "cx", 3: "u2", 4: "u3", 5: "u4", 6: "u5", 7: "u6", 8: "u7"}[kind], qs, m, folded))
+            out.append((pass_i, _lib.K_NAMES[kclass], {1: "u1", 2: "cx", 3: "u2", 4: "u3", 5: "u4", 6: "u5", 7: "u6", 8: "u7", 9: "u8"}[kind], qs, m, folded))
 
         check(_lib.load().qsim_schedule_circuit(self._h, fuse, tile_bits, tile_low_bits, tile_max_ops,
                                                 _lib.SCHED_CB(cb), None))

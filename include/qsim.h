@@ -39,7 +39,7 @@ enum {
 };
 
 /* Gate kinds in a qsim_circuit. */
-enum { QSIM_GATE_U1 = 1, QSIM_GATE_CX = 2, QSIM_GATE_U2 = 3, QSIM_GATE_U3 = 4, QSIM_GATE_U4 = 5, QSIM_GATE_U5 = 6, QSIM_GATE_U6 = 7, QSIM_GATE_U7 = 8 /* U3..U7: scheduler output only */ };
+enum { QSIM_GATE_U1 = 1, QSIM_GATE_CX = 2, QSIM_GATE_U2 = 3, QSIM_GATE_U3 = 4, QSIM_GATE_U4 = 5, QSIM_GATE_U5 = 6, QSIM_GATE_U6 = 7, QSIM_GATE_U7 = 8, QSIM_GATE_U8 = 9 /* U3..U8: scheduler output only */ };
 
 /* Options for qsim_set_option. */
 enum {
@@ -418,9 +418,9 @@ int qsim_plan_circuit(const qsim_circuit *c, int fuse, int tile_bits, int tile_l
  * finds (all ones: a dense state, e.g. a shard after its second exchange; 0: fresh from a reset, what qsim_plan_circuit assumes). */
 int qsim_plan_circuit_from(const qsim_circuit *c, int fuse, int tile_bits, int tile_low_bits, uint64_t initial_support, qsim_stats *out);
 /* Same scheduler, op by op: calls `cb` for every fused block in launch order with the pass it belongs to, the
- * kernel class of that pass, the block kind (QSIM_GATE_U1 / _CX / _U2 .. _U7 by qubit count), its qubits (most
+ * kernel class of that pass, the block kind (QSIM_GATE_U1 / _CX / _U2 .. _U8 by qubit count), its qubits (most
  * significant first; CX: control, target) and its matrix (2^nq x 2^nq complex, row-major; NULL for CX).  A block of a
- * tile pass may span up to 7 qubits: at most 5 inside the tile plus, listed first, at most 2 outside it in which the
+ * tile pass may span up to 8 qubits: at most 6 inside the tile plus, listed first, at most 2 outside it in which the
  * matrix is block-diagonal (they select the sub-block a tile gets).  Lets a CPU test replay the schedule with numpy
  * and compare it with the unfused circuit. */
 typedef void (*qsim_sched_cb)(void *user, int pass, int kernel_class, int kind, const int *qubits, int nq,

@@ -658,6 +658,8 @@ static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, bool 
         }
     if (skips) t.flags |= kOpFlagSkips;
     if (closed) t.flags |= kOpFlagClosed;
+    // what the kernel branches on, in the bit positions it uses (kernels_impl.inc PartPlan::info): log2 T, skips, barrier between reads and writes
+    t.b[7] = (uint8_t)(((T == 4 ? 2 : T == 2 ? 1 : 0) << 1) | (skips ? 8 : 0) | ((K > 3 && !closed) ? 16 : 0));
     return true;
 }
 

@@ -173,18 +173,75 @@ def exchange_model(depth, vocabulary, tile_gbps, ms_per_step_n30, link_gbps=50.0
         sent = sum(x["blocks_sent"] * x["block_bytes"] for x in worst["exchanges"])
         xms = sum((1e3 * x["block_bytes"] / (link_gbps * 1e9)) if (x["blocks_sent"] or x["blocks_received"]) else 0.0 for x in worst["exchanges"])
         ideal = ms_per_step_n30 * (2.0 ** (n - 30)) / P
+        overlap = _price_chunked_exchanges(worst, n - p, shard_bytes, tile_gbps, link_gbps)
         rows.append({"qubits": n, "ranks": P, "exchanges": len(worst["exchanges"]),
                      "qubits_swapped": [x["qubits"] for x in worst["exchanges"]],
                      "local_passes": worst["passes"], "local_sweeps_of_the_shard": worst["sweeps"],
                      "bytes_sent_per_rank": sent, "predicted_exchange_ms": xms,
                      "predicted_local_ms": local_ms, "predicted_step_ms": local_ms + xms,
-                     "ideal_ms": ideal, "vs_ideal": (local_ms + xms) / ideal})
+                     "ideal_ms": ideal, "vs_ideal": (local_ms + xms) / ideal,
+                     "overlappable_sweeps": overlap["overlappable_sweeps"], "overlap_per_exchange": overlap["per_exchange"],
+                     "predicted_step_ms_overlapped": local_ms + xms - overlap["saved_ms"],
+                     "vs_ideal_overlapped": (local_ms + xms - overlap["saved_ms"]) / ideal})
     return {"assumptions": {"link_gbps_per_direction": link_gbps, "tile_kernel_gbps_measured_in_this_run": tile_gbps,
                             "note": "xGMI link ~76.8 GB/s per direction peak (7 x ~153 GB/s bidirectional per GPU), 65 % assumed; "
-                                    "no overlap of exchange and local passes; local term = the shard's own schedule (dense after the "
-                                    "first exchange, sparse before it) at the measured tile-kernel rate; ideal = this run's 1-GPU "
-                                    "n=30 step x 2^(n-30) / ranks"},
+                                    "no overlap of exchange and local passes in predicted_step_ms; local term = the shard's own schedule "
+                                    "(dense after the first exchange, sparse before it) at the measured tile-kernel rate; ideal = this "
+                                    "run's 1-GPU n=30 step x 2^(n-30) / ranks; predicted_step_ms_overlapped = the same with up to three "
+                                    "passes on either side of every exchange run chunk by chunk beside the transfer (priced, not built: "
+                                    "_price_chunked_exchanges)"},
             "configs": rows}
+
+
+def _price_chunked_exchanges(ls, m, shard_bytes, tile_gbps, link_gbps, max_passes=3, max_chunk_bits=3):
+    """Host only: what running the passes around an exchange CHUNK BY CHUNK beside the transfer would save (not built: priced).
+    A k-qubit exchange on 2^k ranks puts one block on each of 2^k - 1 links AT ONCE, so sending block b while block b + 1 is
+    computed hides nothing — every link still carries its block from the moment the last block is ready.  What pipelines is a
+    chunk index over c index bits that are neither swapped out nor inside the tile of the passes involved: the last i passes of
+    the segment in front run chunk by chunk (the packing pass writes chunk x of EVERY block, then all links send their piece of
+    chunk x), and the first j passes behind start on chunk x once every peer's piece of it has arrived — also passes on the
+    incoming qubits, because a chunk holds all values of those.  Three-stage pipeline over C = 2^c chunks:
+        t/C + x/C + h/C + (C - 1) max(t, x, h)/C     instead of     t + x + h.
+    Chosen per exchange: i, j <= max_passes and the c <= max_chunk_bits free bits, whichever saves most under the model
+    (the schedules are the shards' own, as qsim_flush builds them: no pass was moved to make room)."""
+    steps = ls["steps"]
+    sweep_ms = 1e3 * 2.0 * shard_bytes / (tile_gbps * 1e9)
+    out = {"overlappable_sweeps": 0.0, "saved_ms": 0.0, "per_exchange": []}
+    for ex in ls["exchanges"]:
+        i_step = ex["step"]
+        x_ms = (1e3 * ex["block_bytes"] / (link_gbps * 1e9)) if (ex["blocks_sent"] or ex["blocks_received"]) else 0.0
+        before = steps[i_step - 1]["per_pass"] if i_step > 0 and isinstance(steps[i_step - 1], dict) else []
+        after = steps[i_step + 1]["per_pass"] if i_step + 1 < len(steps) and isinstance(steps[i_step + 1], dict) else []
+        lsel = ex["local_positions_out"]
+        k = len(lsel)
+        rest = [b for b in range(m) if b not in lsel]           # old local positions that stay, ascending
+        new_pos = {b: idx for idx, b in enumerate(rest)}         # ... and where they sit afterwards (the incoming qubits take the top k)
+        best = {"saved_ms": 0.0, "tail_passes": 0, "head_passes": 0, "chunk_bits": 0, "tail_sweeps": 0.0, "head_sweeps": 0.0}
+        for i in range(0, min(max_passes, len(before)) + 1):
+            for j in range(0, min(max_passes, len(after)) + 1):
+                if i + j == 0 or x_ms == 0.0:
+                    continue
+                busy = 0
+                for ps in before[len(before) - i:]:
+                    busy |= ps["tile_mask"]
+                free = [b for b in rest if not (busy >> b) & 1]
+                for ps in after[:j]:
+                    free = [b for b in free if not (ps["tile_mask"] >> new_pos[b]) & 1]
+                c = min(max_chunk_bits, len(free))
+                if c == 0:
+                    continue
+                t = sum(ps["sweeps"] for ps in before[len(before) - i:]) * sweep_ms
+                h = sum(ps["sweeps"] for ps in after[:j]) * sweep_ms
+                C = float(1 << c)
+                piped = (t + x_ms + h) / C + (C - 1.0) * max(t, x_ms, h) / C
+                saved = (t + x_ms + h) - piped
+                if saved > best["saved_ms"]:
+                    best = {"saved_ms": saved, "tail_passes": i, "head_passes": j, "chunk_bits": c,
+                            "tail_sweeps": t / sweep_ms, "head_sweeps": h / sweep_ms, "exchange_ms": x_ms}
+        out["per_exchange"].append(best)
+        out["saved_ms"] += best["saved_ms"]
+        out["overlappable_sweeps"] += best["tail_sweeps"] + best["head_sweeps"]
+    return out
 
 
 def _selfcheck_once(dist, device, shard_factory, qubits, depth, seed):

@@ -36,6 +36,11 @@ class QsimStats(ctypes.Structure):
                                          "ms": float(self.k_ms[k])} for k in range(K_COUNT)}}
 
 
+class QsimPassInfo(ctypes.Structure):
+    _fields_ = [("kernel_class", ctypes.c_int32), ("blocks", ctypes.c_int32), ("tile_mask", c_uint64), ("visited", c_double),
+                ("bytes", c_double), ("cost_bytes", c_double)]
+
+
 class QsimTuneReport(ctypes.Structure):
     _fields_ = [("tile_passes", c_int), ("already_known", c_int), ("passes_tuned", c_int), ("passes_reordered", c_int),
                 ("candidates_timed", c_int), ("ms_ascending", c_double), ("ms_best", c_double), ("seconds", c_double)]
@@ -165,6 +170,7 @@ SIGNATURES = {
     "qsim_gate_matrix": (c_int, [c_char_p, _DP]),
     "qsim_plan_circuit": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(QsimStats)]),
     "qsim_plan_circuit_from": (c_int, [c_void_p, c_int, c_int, c_int, c_uint64, POINTER(QsimStats)]),
+    "qsim_plan_passes": (c_int, [c_void_p, c_int, c_int, c_int, c_uint64, POINTER(QsimPassInfo), c_int, POINTER(c_int)]),
     "qsim_schedule_circuit": (c_int, [c_void_p, c_int, c_int, c_int, c_int, SCHED_CB, c_void_p]),
 }
 # include/qsim_legacy.h

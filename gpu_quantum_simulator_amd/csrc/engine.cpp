@@ -2034,6 +2034,37 @@ extern "C" int qsim_plan_circuit_from(const qsim_circuit *c, int fuse, int tile_
     return QSIM_OK;
 }
 
+// The same schedule pass by pass: which qubits each tile pass holds in its tile, how much of the register it visits and what the
+// planning steps price it at.  What a host-side model needs to decide which passes could run chunk by chunk beside an exchange
+// (bench.py exchange_model: a pass can only be pipelined over index bits that are NOT in its tile).
+extern "C" int qsim_plan_passes(const qsim_circuit *c, int fuse, int tile_bits, int tile_low_bits, uint64_t initial_support, qsim_pass_info *out, int cap,
+                                int *count) {
+    if (!c || !count || (cap > 0 && !out)) return fail(QSIM_ERR_ARG, "NULL argument");
+    if (fuse < 0 || fuse > 3) return fail(QSIM_ERR_ARG, "fuse level %d not in 0..3", fuse);
+    Scheduler sched(sched_config(c->num_q, fuse, tile_bits, tile_low_bits, 32, 10, false, initial_support));
+    feed(sched, c);
+    std::vector<Pass> passes;
+    sched.finish(passes);
+    *count = (int)passes.size();
+    for (size_t i = 0; i < passes.size() && (int)i < cap; i++) {
+        const Pass &p = passes[i];
+        qsim_pass_info &o = out[i];
+        o.kernel_class = p.kclass;
+        o.blocks = p.kclass == QSIM_K_TILE ? (int)p.blocks.size() - p.geom.n_scale : 1;
+        o.tile_mask = 0;
+        if (p.kclass == QSIM_K_TILE) {
+            o.tile_mask = (1ULL << p.geom.low_bits) - 1ULL;
+            for (int j = 0; j < p.geom.n_high; j++) o.tile_mask |= 1ULL << p.geom.high[j];
+        } else {
+            o.tile_mask = c->num_q >= 64 ? ~0ULL : ((1ULL << c->num_q) - 1ULL); // a single-gate kernel: treat every bit as touched
+        }
+        o.visited = p.visited;
+        o.bytes = p.bytes * p.visited;
+        o.cost_bytes = pass_cost(p, false);
+    }
+    return QSIM_OK;
+}
+
 extern "C" int qsim_schedule_circuit(const qsim_circuit *c, int fuse, int tile_bits, int tile_low_bits, int tile_max_ops,
                                      qsim_sched_cb cb, void *user) {
     if (!c || !cb) return fail(QSIM_ERR_ARG, "NULL argument");

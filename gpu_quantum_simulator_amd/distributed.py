@@ -115,7 +115,7 @@ class ShardPlan:
                 ro = h.exchange_roles(i, rank)
                 k = len(st[1])
                 out["exchanges"].append({"qubits": k, "blocks_sent": bin(ro["send"]).count("1"), "blocks_received": bin(ro["recv"]).count("1"),
-                                         "block_bytes": (16 << m) >> k})
+                                         "block_bytes": (16 << m) >> k, "local_positions_out": list(st[2]), "step": i})
                 empty, support = bool(ro["empty_after"]), ro["new_support"]
                 out["steps"].append("exchange")
                 continue
@@ -134,7 +134,11 @@ class ShardPlan:
             sweeps = pl["algorithmic_bytes"] / (32.0 * (1 << m))
             out["passes"] += pl["launches"]
             out["sweeps"] += sweeps
-            out["steps"].append({"passes": pl["launches"], "sweeps": sweeps})
+            # pass by pass: the tile bits and the sweeps each pass moves — what decides which passes could run chunk by chunk
+            # beside the exchange in front of or behind them (bench.py exchange_model)
+            per_pass = [{"tile_mask": x["tile_mask"], "sweeps": x["bytes"] / (32.0 * (1 << m)), "blocks": x["blocks"]}
+                        for x in c.passes(initial_support=support)]
+            out["steps"].append({"passes": pl["launches"], "sweeps": sweeps, "per_pass": per_pass})
             support = (1 << m) - 1
         return out
 

@@ -108,6 +108,18 @@ class Circuit:
         check(_lib.load().qsim_plan_circuit_from(self._h, fuse, tile_bits, tile_low_bits, initial_support, byref(st)))
         return st.as_dict()
 
+    def passes(self, fuse: int = 3, tile_bits: int = 12, tile_low_bits: int = 3, initial_support: int = 0) -> list:
+        """qsim_plan_passes: the schedule pass by pass (host only) — kernel class, blocks, the index bits inside the tile, the
+        fraction of the register visited, algorithmic bytes and the bytes-equivalent of the pass-time model."""
+        from ctypes import c_int
+        cap = 4096
+        buf = (_lib.QsimPassInfo * cap)()
+        n = c_int()
+        check(_lib.load().qsim_plan_passes(self._h, fuse, tile_bits, tile_low_bits, initial_support, buf, cap, byref(n)))
+        return [{"kernel": _lib.K_NAMES[buf[i].kernel_class], "blocks": int(buf[i].blocks), "tile_mask": int(buf[i].tile_mask),
+                 "visited": float(buf[i].visited), "bytes": float(buf[i].bytes), "cost_bytes": float(buf[i].cost_bytes)}
+                for i in range(min(n.value, cap))]
+
     def schedule(self, fuse: int = 3, tile_bits: int = 12, tile_low_bits: int = 3, tile_max_ops: int = 32) -> list:
         """Fused blocks in launch order: (pass, kernel_class, kind, qubits, matrix|None, gates_folded); kind is
         "u1" / "cx" / "u2" ... "u8", qubits most significant first (cx: control, target)."""

@@ -417,6 +417,16 @@ int qsim_plan_circuit(const qsim_circuit *c, int fuse, int tile_bits, int tile_l
 /* The same for a run that does not start from a reset: initial_support = index bits that may be 1 in the state the circuit
  * finds (all ones: a dense state, e.g. a shard after its second exchange; 0: fresh from a reset, what qsim_plan_circuit assumes). */
 int qsim_plan_circuit_from(const qsim_circuit *c, int fuse, int tile_bits, int tile_low_bits, uint64_t initial_support, qsim_stats *out);
+/* The same schedule pass by pass (at most `cap` entries are written, *count receives the number of passes): the kernel class,
+ * the blocks of a tile pass, the index bits inside its tile (all bits for a single-gate kernel), the fraction of the register it
+ * visits, its algorithmic bytes and the bytes-equivalent the planning steps price it at (pass-time model).  Host-side models
+ * use it to tell which passes could be pipelined beside an exchange (bench.py exchange_model). */
+typedef struct {
+    int32_t kernel_class, blocks;
+    uint64_t tile_mask;
+    double visited, bytes, cost_bytes;
+} qsim_pass_info;
+int qsim_plan_passes(const qsim_circuit *c, int fuse, int tile_bits, int tile_low_bits, uint64_t initial_support, qsim_pass_info *out, int cap, int *count);
 /* Same scheduler, op by op: calls `cb` for every fused block in launch order with the pass it belongs to, the
  * kernel class of that pass, the block kind (QSIM_GATE_U1 / _CX / _U2 .. _U8 by qubit count), its qubits (most
  * significant first; CX: control, target) and its matrix (2^nq x 2^nq complex, row-major; NULL for CX).  A block of a

@@ -432,3 +432,26 @@ def test_sparse_exchange_protocol_on_poisoned_memory(oracle, tmp_path, world, n,
     assert np.max(np.abs(got - want)) < TOL
     if plans[0].exchanges:
         assert saved_blocks > 0  # the first exchange of a run always has empty shards (the initial global qubits are still |0>)
+
+
+def test_exchange_model_prices_chunked_overlap():
+    """bench.py exchange_model (host only): the plain prediction is exchanges + local passes; the overlapped one runs up to three
+    passes on either side of an exchange chunk by chunk beside the transfer (priced from the shards' own schedules through
+    qsim_plan_passes — a pass can only be chunked over index bits outside its tile).  It can never beat the longer of the two
+    legs, never lose against the serial sum, and every pass it counts must exist."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    model = bench.exchange_model(300, "all", 4400.0, 66.0)
+    assert [(c["qubits"], c["ranks"]) for c in model["configs"]] == [(30, 2), (30, 4), (30, 8), (33, 8)]
+    for c in model["configs"]:
+        plain, piped = c["predicted_step_ms"], c["predicted_step_ms_overlapped"]
+        assert piped <= plain + 1e-9
+        assert piped >= max(c["predicted_exchange_ms"], c["predicted_local_ms"]) - 1e-9
+        assert len(c["overlap_per_exchange"]) == c["exchanges"]
+        for e in c["overlap_per_exchange"]:
+            assert 0 <= e["tail_passes"] <= 3 and 0 <= e["head_passes"] <= 3 and e["saved_ms"] >= 0
+            if e["saved_ms"] > 0:
+                assert 1 <= e["chunk_bits"] <= 3

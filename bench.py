@@ -327,33 +327,48 @@ def run_selfcheck(dist, device, shard_factory=None, require_native=True, qubits=
     return rec
 
 
-def one_shot_cli(n, gates):
-    """The reference's own protocol (quantum_simulator.c:143,244-248; tester.bash:12): ONE process, ONE circuit, the printed
-    seconds run from the header to the last gate.  `bin/qsim <file> 1` as a child process of this one — fresh process, no
-    wisdom file, no planning step: allocation, |0...0>, scheduling, block preparation, uploads and every pass are inside
-    the printed time (only the creation of the HIP context, process start-up, is not)."""
+def one_shot_cli(n, gates, runs=5):
+    """The reference's own protocol (quantum_simulator.c:143,244-248; tester.bash:5-14: five runs, their mean): ONE process, ONE
+    circuit, the printed seconds run from the header to the last gate.  `bin/qsim <file> 1` as a child process of this one —
+    fresh process, no wisdom file, no planning step: allocation, |0...0>, the schedule choice that fits beside the allocation,
+    scheduling, block preparation, uploads and every pass are inside the printed time (only the creation of the HIP context,
+    process start-up, is not).  `runs` children one after the other; printed_seconds / value are the MEDIAN run's, with the
+    minimum and the mean beside them (one sample moved 2 x between boxes: hipMalloc of 16 GiB takes 0.04-0.25 s)."""
+    import statistics
     import subprocess
     import tempfile
     from gpu_quantum_simulator_amd import _lib, circuits
+    samples = []
     with tempfile.TemporaryDirectory() as d:
         path = circuits.write_qasm(os.path.join(d, "one_shot.qasm"), n, gates)
         env = {k: v for k, v in os.environ.items() if not k.startswith("QSIM_")}
         env["QSIM_STATS"] = "1"
-        t0 = time.perf_counter()
-        p = subprocess.run([_lib.CLI_PATH, path, "1"], capture_output=True, text=True, env=env, timeout=900)
-        wall = time.perf_counter() - t0
-    rec = {"command": "bin/qsim <file> 1", "exit_code": p.returncode, "process_wall_seconds": wall}
-    try:
-        rec["printed_seconds"] = float(p.stdout.split()[0])
-        rec["value"] = len(gates) / rec["printed_seconds"]
-        rec["unit"] = "gate-applies/s"
-        stats = [ln for ln in p.stderr.splitlines() if ln.startswith("{")]
-        if stats:
-            st = json.loads(stats[-1])
-            rec["launches"] = st.get("launches")
-            rec["breakdown_s"] = {k: st.get(k) for k in ("parse_s", "allocate_s", "schedule_and_launch_s", "wait_s")}
-    except (ValueError, IndexError):
-        rec["error"] = (p.stdout + p.stderr)[-400:]
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            p = subprocess.run([_lib.CLI_PATH, path, "1"], capture_output=True, text=True, env=env, timeout=900)
+            one = {"exit_code": p.returncode, "process_wall_seconds": time.perf_counter() - t0}
+            try:
+                one["printed_seconds"] = float(p.stdout.split()[0])
+                stats = [ln for ln in p.stderr.splitlines() if ln.startswith("{")]
+                if stats:
+                    st = json.loads(stats[-1])
+                    one["launches"] = st.get("launches")
+                    one["breakdown_s"] = {k: st.get(k) for k in ("parse_s", "allocate_s", "schedule_and_launch_s", "wait_s")}
+            except (ValueError, IndexError):
+                one["error"] = (p.stdout + p.stderr)[-400:]
+            samples.append(one)
+    rec = {"command": "bin/qsim <file> 1", "runs": runs, "exit_code": max(x["exit_code"] for x in samples)}
+    good = sorted((x for x in samples if "printed_seconds" in x), key=lambda x: x["printed_seconds"])
+    if good:
+        med = good[len(good) // 2]
+        rec.update({"printed_seconds": med["printed_seconds"], "value": len(gates) / med["printed_seconds"], "unit": "gate-applies/s",
+                    "printed_seconds_min": good[0]["printed_seconds"], "value_of_the_fastest_run": len(gates) / good[0]["printed_seconds"],
+                    "printed_seconds_mean": statistics.fmean(x["printed_seconds"] for x in good),
+                    "printed_seconds_all": [x["printed_seconds"] for x in samples if "printed_seconds" in x],
+                    "process_wall_seconds": med["process_wall_seconds"], "launches": med.get("launches"),
+                    "breakdown_s": med.get("breakdown_s")})
+    else:
+        rec["error"] = samples[-1].get("error", "no run printed a time")
     return rec
 
 

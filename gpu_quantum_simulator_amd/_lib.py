@@ -69,6 +69,7 @@ SIGNATURES = {
     "qsim_last_error": (c_char_p, []),
     "qsim_create": (c_int, [POINTER(c_void_p), c_int, c_int]),
     "qsim_create_f32": (c_int, [POINTER(c_void_p), c_int, c_int]),
+    "qsim_create_async": (c_int, [POINTER(c_void_p), c_int, c_int, c_int]),
     "qsim_precision_bits": (c_int, [c_void_p]),
     "qsim_create_external": (c_int, [POINTER(c_void_p), c_int, c_int, c_void_p]),
     "qsim_destroy": (None, [c_void_p]),
@@ -146,6 +147,7 @@ SIGNATURES = {
     "qsim_launch_log_visited": (c_int, [c_void_p, c_long, _DP]),
     "qsim_tune_circuit": (c_int, [c_void_p, c_void_p, c_int, c_double, POINTER(QsimTuneReport)]),
     "qsim_choose_schedule": (c_int, [c_void_p, c_void_p]),
+    "qsim_choose_schedule_while_allocating": (c_int, [c_void_p, c_void_p]),
     "qsim_tune_circuit_from": (c_int, [c_void_p, c_void_p, c_int, c_double, POINTER(QsimTuneReport), c_int]),
     "qsim_choose_schedule_for": (c_int, [c_void_p, c_void_p, c_uint64]),
     "qsim_support_after": (c_int, [c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]),

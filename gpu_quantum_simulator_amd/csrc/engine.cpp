@@ -9,6 +9,7 @@
 #include <chrono>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <tuple>
 #include <cstdarg>
 #include <cstdio>
@@ -154,11 +155,26 @@ struct qsim_state {
     int plan_cache = 1;
     long debug_plan_key = 0; // QSIM_OPT_DEBUG_PLAN_KEY: != 0 = every queue gets this key (forced collisions, for the tests of the identity check)
     uint64_t plan_hits = 0, plan_key_collisions = 0; // replays; key matches whose identity differed
+    // qsim_create_async: the amplitude buffer is being allocated by this thread (hipMalloc of 16 GiB takes 0.04-0.25 s) while the
+    // caller parses, sets options and chooses a schedule; whatever needs the buffer joins it first (await_buffer).
+    std::thread alloc_thread;
+    std::atomic<bool> alloc_done{true};
+    hipError_t alloc_err = hipSuccess;
 };
+
+// Joins the allocation of an asynchronously created state; QSIM_ERR_ALLOC ("Malloc error", quantum_simulator.c:170) if it failed.
+static int await_buffer(qsim_state *s) {
+    if (s->alloc_thread.joinable()) s->alloc_thread.join();
+    if (s->alloc_err != hipSuccess) {
+        return fail(s->alloc_err == hipErrorOutOfMemory ? QSIM_ERR_ALLOC : QSIM_ERR_DEVICE, "Malloc error: %s (state needs %zu bytes)",
+                    hipGetErrorString(s->alloc_err), s->amp_bytes() << s->n);
+    }
+    return QSIM_OK;
+}
 
 static constexpr size_t kOpsCap = 512;  // a pass holds <= tile_max_ops blocks; the ring wraps with a stream sync
 
-static int make_state(qsim_state **out, int num_q, int device, void *ext, bool f32 = false) {
+static int make_state(qsim_state **out, int num_q, int device, void *ext, bool f32 = false, bool async = false) {
     if (!out) return fail(QSIM_ERR_ARG, "qsim_create: out is NULL");
     *out = nullptr;
     if (num_q < 0 || num_q > 40) return fail(QSIM_ERR_ARG, "qsim_create: %d qubits unsupported", num_q);
@@ -176,7 +192,17 @@ static int make_state(qsim_state **out, int num_q, int device, void *ext, bool f
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e == hipSuccess) {
         if (ext) s->amps = ext;
-        else { e = hipMalloc(&s->amps, bytes); s->owns = (e == hipSuccess); }
+        else if (async) {
+            s->owns = true;
+            s->alloc_done.store(false);
+            s->alloc_thread = std::thread([s, device, bytes]() {
+                hipError_t ae = hipSetDevice(device);
+                if (ae == hipSuccess) ae = hipMalloc(&s->amps, bytes);
+                if (ae != hipSuccess) { s->amps = nullptr; (void)hipGetLastError(); }
+                s->alloc_err = ae;
+                s->alloc_done.store(true);
+            });
+        } else { e = hipMalloc(&s->amps, bytes); s->owns = (e == hipSuccess); }
     }
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_ops, kOpsCap * sizeof(TileOp));
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_ops, kOpsCap * sizeof(TileOp), hipHostMallocDefault);
@@ -194,6 +220,13 @@ static int make_state(qsim_state **out, int num_q, int device, void *ext, bool f
 
 extern "C" int qsim_create(qsim_state **out, int num_q, int device) { return make_state(out, num_q, device, nullptr); }
 extern "C" int qsim_create_f32(qsim_state **out, int num_q, int device) { return make_state(out, num_q, device, nullptr, true); }
+// The same with the amplitude buffer allocated on a helper thread: returns at once; gates may be queued, options set and a
+// schedule chosen (qsim_choose_schedule_while_allocating) meanwhile, and the first call that needs the buffer waits for it.  An
+// allocation failure surfaces there as QSIM_ERR_ALLOC.
+extern "C" int qsim_create_async(qsim_state **out, int num_q, int device, int precision_bits) {
+    if (precision_bits != 32 && precision_bits != 64) return fail(QSIM_ERR_ARG, "precision must be 32 or 64");
+    return make_state(out, num_q, device, nullptr, precision_bits == 32, true);
+}
 extern "C" int qsim_precision_bits(const qsim_state *s) { return s ? (s->f32 ? 32 : 64) : -1; }
 extern "C" int qsim_create_external(qsim_state **out, int num_q, int device, void *device_amps) {
     if (!device_amps) return fail(QSIM_ERR_ARG, "qsim_create_external: device_amps is NULL");
@@ -202,6 +235,7 @@ extern "C" int qsim_create_external(qsim_state **out, int num_q, int device, voi
 
 extern "C" void qsim_destroy(qsim_state *s) {
     if (!s) return;
+    if (s->alloc_thread.joinable()) s->alloc_thread.join();
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (auto &pe : s->events) { (void)hipEventDestroy(pe.start); (void)hipEventDestroy(pe.stop); }
@@ -228,7 +262,7 @@ extern "C" void *qsim_device_ptr(qsim_state *s) {
 }
 extern "C" void *qsim_stream(qsim_state *s) { return s ? (void *)s->stream : nullptr; }
 // The buffer itself, nothing launched and nothing written first: for a caller that is about to overwrite (part of) it.
-extern "C" void *qsim_state_buffer(qsim_state *s) { return s ? s->amps : nullptr; }
+extern "C" void *qsim_state_buffer(qsim_state *s) { return s && await_buffer(s) == QSIM_OK ? s->amps : nullptr; }
 
 extern "C" int qsim_set_option(qsim_state *s, int option, long value) {
     if (!s) return fail(QSIM_ERR_ARG, "NULL state");
@@ -382,6 +416,7 @@ static void account(qsim_state *s, int kclass, double bytes) {
 // Writes the pending |0...0> with the init kernel (when the next operation cannot generate it itself), or the zeros of a
 // state that has only been written inside its support so far.
 static int materialize_zero_ket(qsim_state *s) {
+    { const int rc = await_buffer(s); if (rc) return rc; }
     if (!s->zero_ket_pending && !s->partial) return QSIM_OK;
     HIP_TRY(hipSetDevice(s->device)); // a cluster drives several devices from one thread
     LaunchCfg cfg{s->stream, s->grid_cap};
@@ -960,6 +995,7 @@ static uint64_t current_support(const qsim_state *s);
 // stays NULL (the caller then runs the pack kernel).
 static int flush_impl(qsim_state *s, PackJob *job) {
     if (!s) return fail(QSIM_ERR_ARG, "NULL state");
+    { const int rc = await_buffer(s); if (rc) return rc; } // (everything that looks at the buffer flushes first: the one place to wait for qsim_create_async)
     if (s->queue.empty()) return QSIM_OK;
     if (s->zero_ket_pending && s->zero_ket_amp == 0.0) { // the all-zero vector (a shard that holds nothing yet): every gate maps it to itself
         s->queue.clear();
@@ -1610,7 +1646,7 @@ static std::vector<QueuedGate> queue_of(const qsim_circuit *c) {
 }
 
 static void choose_schedule(qsim_state *s, const qsim_circuit *c, const SchedConfig &scfg, std::vector<Pass> *out,
-                            std::vector<RankedVariant> *ranked = nullptr, uint64_t *key_out = nullptr) {
+                            std::vector<RankedVariant> *ranked = nullptr, uint64_t *key_out = nullptr, const std::atomic<bool> *stop = nullptr) {
     std::vector<Pass> passes;
     if (s->fuse < 3) {
         Scheduler sv(scfg);
@@ -1655,40 +1691,71 @@ static void choose_schedule(qsim_state *s, const qsim_circuit *c, const SchedCon
         for (int com = 1; com >= 0; com--)
             for (double mar : {scfg.cheap_margin, 2.0 * scfg.cheap_margin})
                 for (int la = scfg.lookahead; la <= scfg.lookahead + (scfg.lookahead >= 1 ? 1 : 0); la++) variants.push_back({com, mar, la, cap, 0});
+    // Every candidate is an independent run of the scheduler on the same gates: they are evaluated on up to eight host threads
+    // (80 schedules at n = 30: 0.9-1.3 s on one thread) and REDUCED in candidate order with the same rule as before — the default
+    // first, a later one only when it is at least 0.5 % cheaper — so the choice does not depend on the thread count.  `stop`
+    // (the cold path of the C host: "plan while the state is being allocated, no longer") ends the search early: candidates not
+    // evaluated by then simply do not take part; the default always does.
+    std::vector<double> costs; // per candidate; < 0: not evaluated
+    auto evaluate = [&](size_t first, size_t last) {
+        costs.resize(last, -1.0);
+        std::atomic<size_t> next{first};
+        auto worker = [&]() {
+            for (;;) {
+                const size_t vi = next.fetch_add(1);
+                if (vi >= last) return;
+                if (vi != 0 && stop && stop->load()) return;
+                Scheduler sv(with_hint(scfg, variants[vi]));
+                feed(sv, c);
+                double cost = 0;
+                sv.finish([&](Pass &&p) { cost += pass_cost(p, s->f32); });
+                costs[vi] = cost;
+            }
+        };
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t nthreads = std::min<size_t>({(size_t)8, (size_t)(hw ? hw : 1), last - first});
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nthreads; t++) pool.emplace_back(worker);
+        worker();
+        for (std::thread &t : pool) t.join();
+    };
     double best_cost = 0;
     size_t best = 0;
-    std::vector<double> costs;
-    auto try_variant = [&](size_t vi) {
-        Scheduler sv(with_hint(scfg, variants[vi]));
-        feed(sv, c);
-        std::vector<Pass> pv;
-        sv.finish(pv);
-        double cost = 0;
-        for (const Pass &p : pv) cost += pass_cost(p, s->f32);
-        costs.push_back(cost);
-        if (ranked) ranked->push_back({variants[vi], cost, vi == 0});
-        if (vi == 0 || cost < best_cost * 0.995) { best_cost = cost; best = vi; passes = std::move(pv); }
+    auto reduce = [&](size_t first, size_t last) {
+        for (size_t vi = first; vi < last; vi++) {
+            if (costs[vi] < 0) continue;
+            if (ranked) ranked->push_back({variants[vi], costs[vi], vi == 0});
+            if (vi == 0 || costs[vi] < best_cost * 0.995) { best_cost = costs[vi]; best = vi; }
+        }
     };
-    for (size_t vi = 0; vi < variants.size(); vi++) try_variant(vi);
+    evaluate(0, variants.size());
+    reduce(0, variants.size());
     // ... and, for the three settings that came out best, the same setting with its ties broken differently (SchedConfig::seed):
     // the greedy packing is sensitive to which of several equally good clusters or qubits it takes first — over 40 seeds the
     // swept bytes of one setting spread by 10 % and more (bench circuit 9.57 -> 8.63 sweeps, another 9.13 -> 8.06)
-    if (variants.size() > 1 || scfg.local_iters > 0) {
-        std::vector<size_t> order(variants.size());
-        for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    if ((variants.size() > 1 || scfg.local_iters > 0) && !(stop && stop->load())) {
+        std::vector<size_t> order;
+        for (size_t i = 0; i < variants.size(); i++)
+            if (costs[i] >= 0) order.push_back(i);
         std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return costs[a] < costs[b]; });
-        const size_t base_count = std::min<size_t>(3, order.size());
+        const size_t base_count = std::min<size_t>(3, order.size()), first_seeded = variants.size();
         constexpr int kSeeds = 16;
         for (size_t b = 0; b < base_count; b++)
             for (int sd = 1; sd <= kSeeds; sd++) {
                 SchedHint h = variants[order[b]];
                 h.seed = (uint64_t)sd;
                 variants.push_back(h);
-                try_variant(variants.size() - 1);
             }
+        evaluate(first_seeded, variants.size());
+        reduce(first_seeded, variants.size());
     }
     set_sched_hint(key, variants[best], best == 0, scfg);
-    if (out) *out = std::move(passes);
+    if (out) { // the passes of the choice (one more run of the scheduler: the candidates kept their costs only)
+        Scheduler sv(with_hint(scfg, variants[best]));
+        feed(sv, c);
+        sv.finish(passes);
+        *out = std::move(passes);
+    }
 }
 
 // The schedule choice alone (no timing): for a run from a reset and for a run on a dense state.
@@ -1702,6 +1769,18 @@ extern "C" int qsim_choose_schedule(qsim_state *s, const qsim_circuit *c) {
         const SchedConfig scfg = sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32, dense ? ~0ULL : 0);
         choose_schedule(s, c, scfg, nullptr);
     }
+    return QSIM_OK;
+}
+
+// The cold path of the C host (bin/qsim: one circuit, one run, quantum_simulator.c:143-248): the schedule choice for a run from a
+// reset, for as long as the state's buffer is still being allocated (qsim_create_async) and no longer — the candidates evaluated
+// by then compete, the default always does.  With a buffer that is already there it returns at once with the default schedule.
+extern "C" int qsim_choose_schedule_while_allocating(qsim_state *s, const qsim_circuit *c) {
+    if (!s || !c) return fail(QSIM_ERR_ARG, "NULL argument");
+    if (c->num_q != s->n) return fail(QSIM_ERR_ARG, "circuit has %d qubits, state has %d", c->num_q, s->n);
+    if (s->alloc_done.load() || s->fuse < 3) return QSIM_OK;
+    const SchedConfig scfg = sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32, s->sparse_start ? 0 : ~0ULL);
+    choose_schedule(s, c, scfg, nullptr, nullptr, nullptr, &s->alloc_done);
     return QSIM_OK;
 }
 

@@ -157,11 +157,16 @@ int main(int argc, char *argv[]) {
     const int device = (v = getenv("QSIM_DEVICE")) && *v ? atoi(v) : 0;
     const int f32 = (v = getenv("QSIM_PRECISION")) && atoi(v) == 32;
     const double t_parsed = wall_seconds();
-    rc = f32 ? qsim_create_f32(&s, qsim_circuit_num_qubits(c), device) : qsim_create(&s, qsim_circuit_num_qubits(c), device);
+    /* The state's buffer is allocated on a helper thread (hipMalloc of 16 GiB: 0.04-0.25 s, the largest single item of a cold
+     * run); meanwhile the options are applied and the schedule is chosen among as many candidates as fit into that wait
+     * (qsim_choose_schedule_while_allocating: the cold run no longer takes the default schedule because choosing cost a second). */
+    rc = qsim_create_async(&s, qsim_circuit_num_qubits(c), device, f32 ? 32 : 64);
     /* One circuit, one run: a second 2^n buffer for out-of-place passes would cost more to allocate (50 ms .. 1 s for 16 GiB,
      * measured) than the ~1.6 % it saves on the passes; QSIM_PINGPONG overrides. */
     if (rc == QSIM_OK) rc = qsim_set_option(s, QSIM_OPT_PINGPONG, 0);
     if (rc == QSIM_OK) rc = qsim_apply_env_options(s);
+    if (rc == QSIM_OK && !((v = getenv("QSIM_TUNE")) && *v && atoi(v))) rc = qsim_choose_schedule_while_allocating(s, c);
+    if (rc == QSIM_OK) rc = qsim_flush(s); /* nothing is queued yet: this only waits for the buffer ("Malloc error" comes from here) */
     const double t_created = wall_seconds();
     double t_plan = 0.0; /* planning is start-up like context creation: not part of the printed time */
     if (rc == QSIM_OK) {

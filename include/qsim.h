@@ -119,6 +119,11 @@ int qsim_create(qsim_state **out, int num_q, int device);
  * qsim_write convert), sums (norm, sampling) still accumulate in fp64.  Not the parity configuration: results agree
  * with quantum_simulator.c to fp32 rounding (~1e-6 per amplitude), not to 1e-10.  Clusters are fp64 only. */
 int qsim_create_f32(qsim_state **out, int num_q, int device);
+/* Same as qsim_create / qsim_create_f32 (precision_bits 64 / 32) with the amplitude buffer allocated on a helper thread: the call
+ * returns at once — hipMalloc of a 16 GiB state takes 0.04-0.25 s, the largest single item of a cold run
+ * (quantum_simulator.c:168-177 has malloc in the same place) — so that parsing, options, gate queueing and the schedule choice
+ * run beside it.  The first call that needs the buffer waits for it; an allocation failure surfaces there as QSIM_ERR_ALLOC. */
+int qsim_create_async(qsim_state **out, int num_q, int device, int precision_bits);
 int qsim_precision_bits(const qsim_state *s); /* 64 or 32; -1 for NULL */
 /* Same, on caller-owned device memory of 16<<num_q bytes (e.g. a torch tensor's storage). */
 int qsim_create_external(qsim_state **out, int num_q, int device, void *device_amps);
@@ -191,6 +196,10 @@ int qsim_tune_circuit(qsim_state *s, const qsim_circuit *circuit, int max_candid
  * bytes for this circuit — for a run from a reset and for a run on a dense state — and returns.  qsim_tune_circuit does
  * this too. */
 int qsim_choose_schedule(qsim_state *s, const qsim_circuit *circuit);
+/* The same choice for a run from a reset, for as long as the buffer of a state made by qsim_create_async is still being allocated
+ * and no longer: the candidates scheduled by then compete (on up to eight host threads), the default always does.  Returns at
+ * once when the buffer is there already.  What bin/qsim does between the parse and the first launch. */
+int qsim_choose_schedule_while_allocating(qsim_state *s, const qsim_circuit *circuit);
 /* The same for a circuit that will run on a state that is NOT fresh from a reset (dense_start != 0): the schedule of such a
  * run differs in its first passes (QSIM_OPT_SPARSE_START), e.g. a shard's local gates after its first exchange. */
 int qsim_tune_circuit_from(qsim_state *s, const qsim_circuit *circuit, int max_candidates, double budget_ms, qsim_tune_report *report,

@@ -112,16 +112,20 @@ def host_ram_bytes():
 
 
 def cpu_baseline(n, gates, budget_s, min_gates=3):
-    """quantum_simulator.c's hot loops (the oracle's restatement of :81-106) on this host, 1 thread, on a bounded
-    sample of the same circuit."""
+    """quantum_simulator.c's hot loops (:81-106) on this host, 1 thread, on a bounded sample of the same circuit.  `kind`
+    "reference": execute_single_qubit_gate / execute_cnot of the REAL quantum_simulator.c, compiled in the build container from
+    the sources where they lie (oracle/Makefile ref -> oracle/_ref/libqsref.so: a build output that travels with the snapshot,
+    git-ignored); "port": the oracle's restatement of the same loops (byte-identical results, tests/test_oracle_golden.py) where
+    that file is absent."""
     import ctypes
 
     import numpy as np
     from oracle import oracle  # the checker, used here only as the timed CPU baseline
 
+    kind = "reference" if oracle.have_reference() else "port"
     need = 16 << n
     if need + (8 << 30) > host_ram_bytes():
-        return {"value": None, "unit": "gate-applies/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
+        return {"value": None, "unit": "gate-applies/s", "cores": 1, "host_cores": os.cpu_count(), "kind": kind,
                 "sample": f"not run: the 2^{n} state ({need >> 30} GiB) does not fit this host's RAM"}
     oracle.build(with_reference=False)
     dp = ctypes.POINTER(ctypes.c_double)
@@ -130,23 +134,29 @@ def cpu_baseline(n, gates, budget_s, min_gates=3):
     state[1:] = 0.0  # touch every page before the clock starts
     sp = state.view(np.float64).ctypes.data_as(dp)
     from gpu_quantum_simulator_amd import gate_matrix
-    L = oracle.lib()
+    if kind == "reference":
+        R = oracle.reference_lib()
+        apply_cx, apply_1q = R.execute_cnot, R.execute_single_qubit_gate
+    else:
+        L = oracle.lib()
+        apply_cx, apply_1q = L.oracle_apply_cx, L.oracle_apply_1q
     done = 0
     t0 = time.perf_counter()
     for g in gates:
         if g[0] == "cx":
-            L.oracle_apply_cx(sp, n, g[1], g[2])
+            apply_cx(sp, n, g[1], g[2])
         else:
             tok = f"rz({g[1]!r})" if g[0] == "rz" else g[0]
             u = np.ascontiguousarray(gate_matrix(tok).T.reshape(4))  # symmetric anyway
-            L.oracle_apply_1q(sp, n, u.view(np.float64).ctypes.data_as(dp), g[-1])
+            apply_1q(sp, n, u.view(np.float64).ctypes.data_as(dp), g[-1])
         done += 1
         if done >= min_gates and time.perf_counter() - t0 >= budget_s:
             break
     dt = time.perf_counter() - t0
     del state
-    return {"value": done / dt, "unit": "gate-applies/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
-            "sample": f"first {done} gate statements of the same n={n} circuit, {dt:.1f} s, 1 thread, state resident in host RAM"}
+    return {"value": done / dt, "unit": "gate-applies/s", "cores": 1, "host_cores": os.cpu_count(), "kind": kind,
+            "sample": f"first {done} gate statements of the same n={n} circuit, {dt:.1f} s, 1 thread, state resident in host RAM"
+                      + ("; the compiled quantum_simulator.c itself (oracle/_ref)" if kind == "reference" else "; the oracle's restatement of quantum_simulator.c:81-106")}
 
 
 def exchange_model(depth, vocabulary, tile_gbps, ms_per_step_n30, link_gbps=50.0, pack_gbps=5000.0):

@@ -195,13 +195,19 @@ static int make_state(qsim_state **out, int num_q, int device, void *ext, bool f
         else if (async) {
             s->owns = true;
             s->alloc_done.store(false);
-            s->alloc_thread = std::thread([s, device, bytes]() {
-                hipError_t ae = hipSetDevice(device);
-                if (ae == hipSuccess) ae = hipMalloc(&s->amps, bytes);
-                if (ae != hipSuccess) { s->amps = nullptr; (void)hipGetLastError(); }
-                s->alloc_err = ae;
+            try {
+                s->alloc_thread = std::thread([s, device, bytes]() {
+                    hipError_t ae = hipSetDevice(device);
+                    if (ae == hipSuccess) ae = hipMalloc(&s->amps, bytes);
+                    if (ae != hipSuccess) { s->amps = nullptr; (void)hipGetLastError(); }
+                    s->alloc_err = ae;
+                    s->alloc_done.store(true);
+                });
+            } catch (...) { // no thread to be had: allocate here, like qsim_create
                 s->alloc_done.store(true);
-            });
+                e = hipMalloc(&s->amps, bytes);
+                s->owns = (e == hipSuccess);
+            }
         } else { e = hipMalloc(&s->amps, bytes); s->owns = (e == hipSuccess); }
     }
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_ops, kOpsCap * sizeof(TileOp));

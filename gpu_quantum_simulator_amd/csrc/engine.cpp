@@ -1786,6 +1786,17 @@ extern "C" int qsim_choose_schedule_while_allocating(qsim_state *s, const qsim_c
     if (c->num_q != s->n) return fail(QSIM_ERR_ARG, "circuit has %d qubits, state has %d", c->num_q, s->n);
     if (s->alloc_done.load() || s->fuse < 3) return QSIM_OK;
     const SchedConfig scfg = sched_config(s->n, s->fuse, s->tile_bits, s->tile_low_bits, s->tile_max_ops, s->tile_pad_from, s->f32, s->sparse_start ? 0 : ~0ULL);
+    { // the tile kernel's code object is loaded at its first use: here, beside the allocation, instead of in front of the first pass
+        HIP_TRY(hipSetDevice(s->device));
+        TileGeom g{};
+        g.tile_bits = std::min(scfg.tile_bits, s->n);
+        g.low_bits = std::min(scfg.tile_low_bits, g.tile_bits);
+        g.n_high = g.tile_bits - g.low_bits;
+        g.n = s->n;
+        LaunchCfg cfg{s->stream, s->grid_cap, true};
+        (void)launch_tile(cfg, nullptr, nullptr, s->f32, g, nullptr, 0, s->tile_threads, false, 1.0);
+        (void)hipGetLastError();
+    }
     choose_schedule(s, c, scfg, nullptr, nullptr, nullptr, &s->alloc_done);
     return QSIM_OK;
 }

@@ -98,6 +98,7 @@ struct PackMap {
 struct LaunchCfg {
     hipStream_t stream;
     int grid_cap; // 0 = one workgroup per work tile
+    bool warm_only = false; // launch_tile: load the kernel's code object and set its attributes, launch nothing (the cold path does this while the state is being allocated)
 };
 
 // All launchers are asynchronous on cfg.stream and return the hipError_t of the launch.  `f32` selects the amplitude

@@ -145,6 +145,7 @@ SIGNATURES = {
     "qsim_launch_log": (c_long, [c_void_p, c_long, POINTER(c_int), POINTER(c_int), POINTER(c_uint64), POINTER(c_double)]),
     "qsim_launch_log_order": (c_int, [c_void_p, c_long, POINTER(c_int), POINTER(c_int)]),
     "qsim_launch_log_visited": (c_int, [c_void_p, c_long, _DP]),
+    "qsim_launch_log_blocks": (c_int, [c_void_p, c_long, c_void_p, c_int, POINTER(c_int)]),
     "qsim_tune_circuit": (c_int, [c_void_p, c_void_p, c_int, c_double, POINTER(QsimTuneReport)]),
     "qsim_choose_schedule": (c_int, [c_void_p, c_void_p]),
     "qsim_choose_schedule_while_allocating": (c_int, [c_void_p, c_void_p]),

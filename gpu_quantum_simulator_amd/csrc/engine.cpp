@@ -75,8 +75,9 @@ struct ProfEvent {
     uint64_t high_mask;
     uint64_t order_code; // tile passes: the high tile bits in tile-local order, 5 bits each, lowest first
     double visited;      // tile passes: fraction of the register's tiles the pass works on (the state's support)
+    std::vector<uint8_t> forms; // tile passes: one byte per block (qsim_launch_log_blocks)
 };
-struct LaunchRec { int kclass, n_ops; uint64_t high_mask; double ms; uint64_t order_code; double visited; };
+struct LaunchRec { int kclass, n_ops; uint64_t high_mask; double ms; uint64_t order_code; double visited; std::vector<uint8_t> forms; };
 
 // Everything a schedule depends on: the options that shape it, the state's support, the QSIM_SCHED_* overrides and the
 // gates themselves.  A cached plan is only replayed for a queue whose identity EQUALS the one it was built from, field by
@@ -153,6 +154,7 @@ struct qsim_state {
     std::vector<struct CachedPlan> plans;
     uint64_t plan_clock = 0;
     int plan_cache = 1;
+    int tune_schedules = 4; // qsim_tune_circuit: how many of the model's best schedules are run (QSIM_TUNE_SCHEDULES)
     long debug_plan_key = 0; // QSIM_OPT_DEBUG_PLAN_KEY: != 0 = every queue gets this key (forced collisions, for the tests of the identity check)
     uint64_t plan_hits = 0, plan_key_collisions = 0; // replays; key matches whose identity differed
     // qsim_create_async: the amplitude buffer is being allocated by this thread (hipMalloc of 16 GiB takes 0.04-0.25 s) while the
@@ -380,7 +382,7 @@ static int resolve_events(qsim_state *s) {
     for (auto &pe : s->events) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) s->stats.k_ms[pe.kclass] += ms;
-        if (s->launch_log.size() < (1u << 20)) s->launch_log.push_back({pe.kclass, pe.n_ops, pe.high_mask, (double)ms, pe.order_code, pe.visited});
+        if (s->launch_log.size() < (1u << 20)) s->launch_log.push_back({pe.kclass, pe.n_ops, pe.high_mask, (double)ms, pe.order_code, pe.visited, std::move(pe.forms)});
         s->event_pool.push_back(pe.start);
         s->event_pool.push_back(pe.stop);
     }
@@ -892,6 +894,20 @@ static int launch_pass(qsim_state *s, const Pass &p, const TileGeom *cached_geom
         else if (s->partial) zero_mask = nmask & ~s->support;
         visited = 1.0 / (double)(1ULL << __builtin_popcountll(zero_mask & ~tmask));
         LaunchScope scope(s, p.kclass, (int)p.blocks.size(), hm, oc, visited);
+        if (scope.on) // what the blocks look like, for the pass-time model's data (tools/pass_model_data.py)
+            for (size_t k = (size_t)geom.n_scale; k < p.blocks.size(); k++) {
+                const TileBlock &b = p.blocks[k];
+                int T = 0;
+                std::vector<std::vector<int>> rows, cols;
+                if (!b.classes(T, rows, cols)) T = 4;
+                int ident = 0; // rows that are identity in every bank
+                for (int r = 0; r < b.dim(); r++) {
+                    bool id = true;
+                    for (int v = 0; v < b.banks() && id; v++) { const auto &rw = b.row(v, r); id = rw.n == 1 && rw.col[0] == r && rw.val[0] == cd(1, 0); }
+                    ident += id;
+                }
+                scope.pe.forms.push_back((uint8_t)((T == 4 ? 2 : T == 2 ? 1 : 0) | (b.nq << 2) | (2 * ident >= b.dim() ? 32 : 0) | (b.ns << 6)));
+            }
         const int rc = cached_ops ? launch_tile_prepared(s, geom, cached_ops, (int)p.blocks.size(), from_zero_ket, oop, zero_mask, job)
                                   : launch_tile_pass(s, p, geom, from_zero_ket, capture, oop, zero_mask, job);
         if (rc) return rc;
@@ -1554,6 +1570,16 @@ extern "C" int qsim_launch_log_visited(qsim_state *s, long index, double *visite
     return QSIM_OK;
 }
 
+extern "C" int qsim_launch_log_blocks(qsim_state *s, long index, uint8_t *codes, int cap, int *count) {
+    if (!s || !count) return QSIM_ERR_ARG;
+    if (resolve_events(s)) return QSIM_ERR_DEVICE;
+    if (index < 0 || index >= (long)s->launch_log.size()) return QSIM_ERR_ARG;
+    const std::vector<uint8_t> &f = s->launch_log[index].forms;
+    *count = (int)f.size();
+    for (int j = 0; codes && j < cap && j < (int)f.size(); j++) codes[j] = f[j];
+    return QSIM_OK;
+}
+
 extern "C" long qsim_launch_log(qsim_state *s, long index, int *kclass, int *n_ops, uint64_t *high_mask, double *ms) {
     if (!s) return -1;
     if (resolve_events(s)) return -1;
@@ -1697,7 +1723,7 @@ static void choose_schedule(qsim_state *s, const qsim_circuit *c, const SchedCon
         for (int com = 1; com >= 0; com--)
             for (double mar : {scfg.cheap_margin, 2.0 * scfg.cheap_margin})
                 for (int la = scfg.lookahead; la <= scfg.lookahead + (scfg.lookahead >= 1 ? 1 : 0); la++) variants.push_back({com, mar, la, cap, 0});
-    // Every candidate is an independent run of the scheduler on the same gates: they are evaluated on up to eight host threads
+    // Every candidate is an independent run of the scheduler on the same gates: they are evaluated on up to 16 host threads
     // (80 schedules at n = 30: 0.9-1.3 s on one thread) and REDUCED in candidate order with the same rule as before — the default
     // first, a later one only when it is at least 0.5 % cheaper — so the choice does not depend on the thread count.  `stop`
     // (the cold path of the C host: "plan while the state is being allocated, no longer") ends the search early: candidates not
@@ -1719,7 +1745,7 @@ static void choose_schedule(qsim_state *s, const qsim_circuit *c, const SchedCon
             }
         };
         const unsigned hw = std::thread::hardware_concurrency();
-        const size_t nthreads = std::min<size_t>({(size_t)8, (size_t)(hw ? hw : 1), last - first});
+        const size_t nthreads = std::min<size_t>({(size_t)16, (size_t)(hw ? hw : 1), last - first}); // a GPU's share of its host's cores
         std::vector<std::thread> pool;
         for (size_t t = 1; t < nthreads; t++) pool.emplace_back(worker);
         worker();
@@ -1887,11 +1913,12 @@ extern "C" int qsim_tune_circuit_support(qsim_state *s, const qsim_circuit *c, i
     if (max_candidates > 1 && s->fuse >= 3 && ranked.size() > 1) {
         std::stable_sort(ranked.begin(), ranked.end(), [](const RankedVariant &a, const RankedVariant &b) { return a.cost < b.cost; });
         std::vector<RankedVariant> tries;
+        if (const char *v = getenv("QSIM_TUNE_SCHEDULES")) s->tune_schedules = std::max(1, std::min(80, atoi(v)));
         for (const RankedVariant &v : ranked) { // distinct predicted costs = (almost surely) distinct schedules
             bool dup = false;
             for (const RankedVariant &t : tries) dup = dup || t.cost == v.cost;
             if (!dup) tries.push_back(v);
-            if (tries.size() == 4) break;
+            if (tries.size() == (size_t)s->tune_schedules) break;
         }
         hipEvent_t t0 = nullptr, t1 = nullptr;
         HIP_TRY(hipEventCreate(&t0));

@@ -370,6 +370,19 @@ class Simulator:
             out.append([order[j] for j in range(cnt.value)])
         return out
 
+    def launch_log_blocks(self) -> list:
+        """Per launch since reset_stats: [(entries_per_row, tile_qubits, mostly_identity, selector_qubits)] of a tile pass's blocks
+        ([] for other kernels) — qsim_launch_log_blocks, the data behind the pass-time model."""
+        from ctypes import c_ubyte
+        lib = _lib.load()
+        n = lib.qsim_launch_log(self._h, -1, None, None, None, None)
+        out = []
+        for i in range(max(n, 0)):
+            codes, cnt = (c_ubyte * 64)(), c_int()
+            check(lib.qsim_launch_log_blocks(self._h, i, codes, 64, byref(cnt)))
+            out.append([(1 << (codes[j] & 3), (codes[j] >> 2) & 7, bool(codes[j] & 32), codes[j] >> 6) for j in range(min(cnt.value, 64))])
+        return out
+
     def reset_stats(self) -> None:
         check(_lib.load().qsim_reset_stats(self._h))
 

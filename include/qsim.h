@@ -197,7 +197,7 @@ int qsim_tune_circuit(qsim_state *s, const qsim_circuit *circuit, int max_candid
  * this too. */
 int qsim_choose_schedule(qsim_state *s, const qsim_circuit *circuit);
 /* The same choice for a run from a reset, for as long as the buffer of a state made by qsim_create_async is still being allocated
- * and no longer: the candidates scheduled by then compete (on up to eight host threads), the default always does.  Returns at
+ * and no longer: the candidates scheduled by then compete (on up to 16 host threads), the default always does.  Returns at
  * once when the buffer is there already.  What bin/qsim does between the parse and the first launch. */
 int qsim_choose_schedule_while_allocating(qsim_state *s, const qsim_circuit *circuit);
 /* The same for a circuit that will run on a state that is NOT fresh from a reset (dense_start != 0): the schedule of such a
@@ -394,6 +394,10 @@ int qsim_launch_log_order(qsim_state *s, long index, int *order, int *count);
 /* ... and the fraction of the register's tiles it worked on (1 for a full sweep and for other kernels; less while the state's
  * support is partial, QSIM_OPT_SPARSE_START / qsim_set_support). */
 int qsim_launch_log_visited(qsim_state *s, long index, double *visited);
+/* ... and what its blocks looked like, one byte per block in order (tile passes; *count = 0 otherwise; at most `cap` are written):
+ * bits 0-1 log2 of the entries per row the block is evaluated with (1, 2 or 4), bits 2-4 its qubits inside the tile, bit 5 set when
+ * at least half of its rows are identity rows, bits 6-7 its selector qubits outside the tile.  Data for the pass-time model. */
+int qsim_launch_log_blocks(qsim_state *s, long index, uint8_t *codes, int cap, int *count);
 
 /* ---- circuits: the tokenizer of compute_state_vector (quantum_simulator.c:115-254) ---------------- */
 /* Parses the OPENQASM-3 subset of quantum_simulator.c (two header statements, `qubit[n] q;` or

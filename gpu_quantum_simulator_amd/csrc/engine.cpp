@@ -283,7 +283,7 @@ extern "C" int qsim_set_option(qsim_state *s, int option, long value) {
         if (value < 0 || value > 3) return fail(QSIM_ERR_ARG, "fuse level %ld not in 0..3", value);
         s->fuse = (int)value;
         break;
-    case QSIM_OPT_PROFILE: s->profile = value != 0; break;
+    case QSIM_OPT_PROFILE: s->profile = value < 0 ? 0 : value > 2 ? 2 : (int)value; break;
     case QSIM_OPT_TILE_BITS:
         if (value < 8 || value > (s->f32 ? 14 : 13)) return fail(QSIM_ERR_ARG, "tile_bits %ld not in 8..%d", value, s->f32 ? 14 : 13);
         s->tile_bits = (int)value;
@@ -894,7 +894,7 @@ static int launch_pass(qsim_state *s, const Pass &p, const TileGeom *cached_geom
         else if (s->partial) zero_mask = nmask & ~s->support;
         visited = 1.0 / (double)(1ULL << __builtin_popcountll(zero_mask & ~tmask));
         LaunchScope scope(s, p.kclass, (int)p.blocks.size(), hm, oc, visited);
-        if (scope.on) // what the blocks look like, for the pass-time model's data (tools/pass_model_data.py)
+        if (scope.on && s->profile >= 2) // what the blocks look like, for the pass-time model's data (tools/pass_model_data.py); host work per launch: only on request
             for (size_t k = (size_t)geom.n_scale; k < p.blocks.size(); k++) {
                 const TileBlock &b = p.blocks[k];
                 int T = 0;

@@ -171,7 +171,7 @@ class Simulator:
         if fuse is not None:
             self.set_option(_lib.OPT_FUSE, fuse)
         if profile:
-            self.set_option(_lib.OPT_PROFILE, 1)
+            self.set_option(_lib.OPT_PROFILE, int(profile))  # True / 1: HIP events per launch; 2: block forms as well (launch_log_blocks)
         names = {"tile_bits": _lib.OPT_TILE_BITS, "tile_low_bits": _lib.OPT_TILE_LOW_BITS,
                  "max_pending": _lib.OPT_MAX_PENDING, "tile_max_ops": _lib.OPT_TILE_MAX_OPS,
                  "grid_cap": _lib.OPT_GRID_CAP, "tile_threads": _lib.OPT_TILE_THREADS,

@@ -51,7 +51,7 @@ enum {
      *      launch, op list read from device memory  (idea of quantum_simulator_preproces_constant.cu:169-178,
      *      done with a full grid)                   [default]                                        */
     QSIM_OPT_FUSE = 1,
-    QSIM_OPT_PROFILE = 2,      /* 1: bracket every launch with HIP events on the engine's stream */
+    QSIM_OPT_PROFILE = 2,      /* 1: bracket every launch with HIP events on the engine's stream; 2: also record each tile pass's block forms (qsim_launch_log_blocks) */
     QSIM_OPT_TILE_BITS = 3,    /* log2 amplitudes per LDS tile for level 3 (8..13, default 12 = 64 KiB) */
     QSIM_OPT_TILE_LOW_BITS = 4,/* contiguous low index bits always inside a tile (2..6, default 3 -> 128-B runs, 9 free high-qubit slots) */
     QSIM_OPT_MAX_PENDING = 5,  /* queued gates that force a flush (default 1<<16) */
@@ -396,7 +396,8 @@ int qsim_launch_log_order(qsim_state *s, long index, int *order, int *count);
 int qsim_launch_log_visited(qsim_state *s, long index, double *visited);
 /* ... and what its blocks looked like, one byte per block in order (tile passes; *count = 0 otherwise; at most `cap` are written):
  * bits 0-1 log2 of the entries per row the block is evaluated with (1, 2 or 4), bits 2-4 its qubits inside the tile, bit 5 set when
- * at least half of its rows are identity rows, bits 6-7 its selector qubits outside the tile.  Data for the pass-time model. */
+ * at least half of its rows are identity rows, bits 6-7 its selector qubits outside the tile.  Recorded under QSIM_OPT_PROFILE = 2
+ * only (host work per launch).  Data for the pass-time model. */
 int qsim_launch_log_blocks(qsim_state *s, long index, uint8_t *codes, int cap, int *count);
 
 /* ---- circuits: the tokenizer of compute_state_vector (quantum_simulator.c:115-254) ---------------- */

@@ -880,6 +880,9 @@ def test_plan_cache_replays_identical_queues_only(oracle, tmp_path):
             logs.append([(k, nops, hm) for k, nops, hm, _ in sim.launch_log()])
         assert logs[0] == logs[1] == logs[2] and len(logs[0]) >= 2
         # the block forms of the same launches (qsim_launch_log_blocks): one per block of a tile pass, replays included
+        sim.set_option(_lib.OPT_PROFILE, 2)
+        sim.reset(); sim.reset_stats(); sim.run(c); sim.sync()
+        assert [(k, nops, hm) for k, nops, hm, _ in sim.launch_log()] == logs[2]
         for (k, nops, _), forms in zip(logs[2], sim.launch_log_blocks()):
             assert (len(forms) <= nops and len(forms) >= 1) if k == "tile" else forms == []
             assert all(t in (1, 2, 4) and 1 <= q <= 6 and 0 <= sel <= 2 for t, q, _, sel in forms)

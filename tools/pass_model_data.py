@@ -13,7 +13,7 @@ variants = [{}, {"QSIM_SCHED_CAP": "28"}, {"QSIM_SCHED_CAP": "32"}, {"QSIM_SCHED
             {"QSIM_SCHED_MERGEQ": "4", "QSIM_SCHED_CAP": "48"}, {"QSIM_SCHED_MERGEQ": "5", "QSIM_SCHED_CAP": "24"}]
 lib = _lib.load()
 print("visited,blocks,ms,high_mask,forms")  # forms: one hex byte per block (qsim_launch_log_blocks)
-with Simulator(n, profile=True, precision=precision) as sim:
+with Simulator(n, profile=2, precision=precision) as sim:
     for env in variants:
         for k in list(os.environ):
             if k.startswith("QSIM_SCHED_"):

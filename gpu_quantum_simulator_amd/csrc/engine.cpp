@@ -1719,8 +1719,10 @@ static void choose_schedule(qsim_state *s, const qsim_circuit *c, const SchedCon
     if (scfg.tail_max_ops > scfg.tile_max_ops) // the engine's own cap is in force (engine_sched_config), not a caller's
         for (int cap : {24, 28, 32, 40})
             if (cap != scfg.tile_max_ops) caps.push_back(cap);
-    for (int cap : caps)
-        for (int com = 1; com >= 0; com--)
+    // (commuting clusters first: over 16 seeded 1000-gate circuits at n = 30 a schedule without them never came within 15 % of the best
+    // of these candidates, so a search that is cut short — `stop` — spends its time on the half that wins)
+    for (int com = 1; com >= 0; com--)
+        for (int cap : caps)
             for (double mar : {scfg.cheap_margin, 2.0 * scfg.cheap_margin})
                 for (int la = scfg.lookahead; la <= scfg.lookahead + (scfg.lookahead >= 1 ? 1 : 0); la++) variants.push_back({com, mar, la, cap, 0});
     // Every candidate is an independent run of the scheduler on the same gates: they are evaluated on up to 16 host threads

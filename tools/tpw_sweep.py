@@ -9,12 +9,12 @@ ntiles = 1 << (n - 12)
 with Simulator(n) as sim:
     sim.tune(c, 48, 8000.0)
     for rep in range(2):
-        for tpw in ({28: (0, 8, 16, 32, 64), 30: (0, 8, 32, 64, 128), 32: (0, 8, 64, 128, 256, 512)}.get(n, (0, 8, 16, 32, 64))):
+        for tpw in ({24: (0, 16, 8, 4, 2), 25: (0, 16, 8, 4, 2), 26: (0, 32, 16, 8, 4), 28: (0, 8, 16, 32, 64), 30: (0, 8, 32, 64, 128), 32: (0, 8, 64, 128, 256, 512)}.get(n, (0, 8, 16, 32, 64))):
             sim.set_option(_lib.OPT_GRID_CAP, ntiles // tpw if tpw else 0)
             for _ in range(2):
                 sim.reset(); sim.run(c); sim.sync()
             t0 = time.time()
-            steps = 10 if n <= 30 else 4
+            steps = (10 if n <= 30 else 4) * (8 if n <= 26 else 1)
             for _ in range(steps):
                 sim.reset(); sim.run(c); sim.sync()
             print(f"n {n} tiles per workgroup {tpw:3d}: {(time.time() - t0) * 1e3 / steps:.2f} ms/step", flush=True)

@@ -14,8 +14,7 @@ namespace qsim {
 struct M2 { double re[4], im[4]; };
 struct M4 { double re[16], im[16]; };
 
-// One fused block inside a cache-blocked pass = one trip of the tile through LDS.  Bit positions are TILE-LOCAL (see TileGeom),
-// ascending: b[0] is the block's lowest qubit = bit 0 of a slot code, b[k-1] its highest = the slot code's top bit.
+// One fused block inside a cache-blocked pass = one trip of the tile through LDS.  Bit positions are TILE-LOCAL (see TileGeom).
 //
 //   TOP_PART   sparse 2^k x 2^k block on k = nq in {3..6} tile qubits, `terms` = T (1, 2 or 4) entries per row.  Per bank the
 //              block is a direct sum of small dense matrices in a permuted basis (Scheduler / TileBlock::classes), so its rows
@@ -64,7 +63,7 @@ struct TileOp {
     uint8_t selbit[2];    // dword 1: their global index bits, most significant bank bit first
     uint8_t ident;        //   bit v: bank v is the identity
     uint8_t flags;        //   kOpFlagSkips: some class is skipped; kOpFlagClosed: no barrier between reads and writes
-    uint8_t b[8];         // dwords 2-3: tile-local bits of the block's qubits, ascending (kMaxOpQ used)
+    uint8_t b[8];         // dwords 2-3.  TOP_PART: nibble a of b[0..4] = the free tile-local bit that bit a of a lane's group index walks (15: none; engine.cpp to_tile_op picks bank-conflict-free ones), b[7] = log2 T << 1 | skips << 3 | barrier << 4.  Pair / quad forms: b[0], b[1] = the block's tile-local bits, ascending
     uint32_t pad0[4];
     double scale[kMaxBanks][2]; // TOP_SCALE: the factor per bank as (re, im); fp32 states: two floats in the first 8 bytes
     uint32_t pad1[8];

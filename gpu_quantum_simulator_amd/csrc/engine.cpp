@@ -656,32 +656,71 @@ static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, bool 
         // (swizzled) unit images of the bits walked by l0, l1, l2 ^ l3, l2 ^ l4 are independent; a ds_write_b128 the 8 lanes of l0..l2
         // when theirs are independent modulo 8 units.  The layout swizzle makes that true for holes-free low bits; a block's qubits
         // punch holes, and the ascending assignment then collides for many hole patterns (24 % of the LDS-active cycles of the bench
-        // schedule were bank conflicts).  fp32 states (8-byte slots, other lane groups) keep the ascending assignment.
+        // schedule were bank conflicts).  fp32 states (8-byte slots) have other lane groups and their own conditions, below.
         int freeb[16], nf = 0;
         for (int lb = 0; lb < g.tile_bits; lb++)
             if (!(used >> lb & 1u)) freeb[nf++] = lb;
-        auto image = [&](int b) -> uint32_t { // unit bits 0..3 of the swizzled slot 1 << b (= sw_slot of kernels_impl.inc, fp64)
+        auto image = [&](int b) -> uint32_t { // unit bits of the swizzled slot 1 << b (= sw_slot of kernels_impl.inc)
+            if (f32) { // 8-byte slots: unit = slot bits 0..4
+                if (b < 5) return 1u << b;
+                if (b < 10) return (1u << (b - 5)) | (1u << ((b - 4) % 5));
+                return (7u << (b - 10)) & 31u;
+            }
             if (b < 4) return 1u << b;
             const int j = (b - 4) % 5;
             return j == 0 ? 15u : 1u << (j - 1);
         };
-        auto rank4 = [](uint32_t a, uint32_t b, uint32_t c, uint32_t d) { // are four vectors of GF(2)^4 independent?
-            uint32_t v[4] = {a, b, c, d};
-            int r = 0;
-            for (int bit = 0; bit < 4; bit++) {
+        auto rank_of = [](std::initializer_list<uint32_t> vs) { // rank of a few vectors of GF(2)^5
+            uint32_t v[5] = {0, 0, 0, 0, 0};
+            int n = 0, r = 0;
+            for (uint32_t x : vs) v[n++] = x;
+            for (int bit = 0; bit < 5; bit++) {
                 int piv = -1;
-                for (int i = r; i < 4; i++)
+                for (int i = r; i < n; i++)
                     if (v[i] >> bit & 1u) { piv = i; break; }
                 if (piv < 0) continue;
                 std::swap(v[r], v[piv]);
-                for (int i = 0; i < 4; i++)
+                for (int i = 0; i < n; i++)
                     if (i != r && (v[i] >> bit & 1u)) v[i] ^= v[r];
                 r++;
             }
-            return r == 4;
+            return r;
         };
+        auto rank4 = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return rank_of({a, b, c, d}) == 4; };
         int order[16];
         for (int i = 0; i < nf; i++) order[i] = freeb[i];
+        if (f32 && nf >= 5) {
+            // fp32: a ds_read_b64 serves the 32 lanes of a half in one cycle when they hit 32 different 8-byte units of a 256-byte row
+            // (the images of l0 .. l4 independent in GF(2)^5), a ds_write_b64 16 contiguous lanes out of a 128-byte row (l0 .. l3
+            // independent modulo 16 units)
+            int best[5] = {-1, -1, -1, -1, -1}, best_score = -1;
+            for (int a0 = 0; a0 < nf && best_score < 2; a0++)
+                for (int a1 = 0; a1 < nf && best_score < 2; a1++) {
+                    if (a1 == a0) continue;
+                    for (int a2 = 0; a2 < nf && best_score < 2; a2++) {
+                        if (a2 == a0 || a2 == a1) continue;
+                        for (int a3 = 0; a3 < nf && best_score < 2; a3++) {
+                            if (a3 == a0 || a3 == a1 || a3 == a2) continue;
+                            const uint32_t v0 = image(freeb[a0]), v1 = image(freeb[a1]), v2 = image(freeb[a2]), v3 = image(freeb[a3]);
+                            if (rank_of({v0, v1, v2, v3}) < 4) continue;
+                            const bool writes_ok = rank_of({v0 & 15u, v1 & 15u, v2 & 15u, v3 & 15u}) == 4;
+                            for (int a4 = 0; a4 < nf && best_score < 2; a4++) {
+                                if (a4 == a0 || a4 == a1 || a4 == a2 || a4 == a3) continue;
+                                if (rank_of({v0, v1, v2, v3, image(freeb[a4])}) < 5) continue;
+                                const int score = writes_ok ? 2 : 1;
+                                if (score > best_score) { best_score = score; best[0] = a0; best[1] = a1; best[2] = a2; best[3] = a3; best[4] = a4; }
+                            }
+                        }
+                    }
+                }
+            if (best_score > 0) {
+                bool taken[16] = {false};
+                int n_o = 0;
+                for (int i = 0; i < 5; i++) { order[n_o++] = freeb[best[i]]; taken[best[i]] = true; }
+                for (int i = 0; i < nf; i++)
+                    if (!taken[i]) order[n_o++] = freeb[i];
+            }
+        }
         if (!f32 && nf >= 5) {
             int best[5] = {-1, -1, -1, -1, -1}, best_score = -1;
             for (int a0 = 0; a0 < nf && best_score < 2; a0++)
@@ -721,8 +760,13 @@ static bool to_tile_op(const TileGeom &g, const TileBlock &blk, TileOp &t, bool 
     auto slot_off = [&](int code) {
         uint32_t o = 0;
         for (int a = 0; a < K; a++) o |= (uint32_t)((code >> a) & 1) << qbit[a];
-        const uint32_t hi = o >> 4, f = (hi ^ (hi >> 5) ^ (hi >> 10)) & 31u; // = sw_fold of kernels_impl.inc
-        if (f32) return (o ^ ((0u - (hi & 1u)) & 15u)) << amp_shift;         // fp32 states keep the bit-4-only swizzle
+        if (f32) { // = sw_fold of kernels_impl.inc for 8-byte slots: the unit is slot bits 0..4
+            const uint32_t hi = o >> 5, a = hi & 31u, b = (hi >> 5) & 7u;
+            const uint32_t fa = a ^ (((a << 1) | (a >> 4)) & 31u);
+            const uint32_t fb = ((0u - (b & 1u)) & 7u) ^ ((0u - ((b >> 1) & 1u)) & 14u) ^ ((0u - ((b >> 2) & 1u)) & 28u);
+            return (o ^ fa ^ fb) << amp_shift;
+        }
+        const uint32_t hi = o >> 4, f = (hi ^ (hi >> 5) ^ (hi >> 10)) & 31u; // = sw_fold of kernels_impl.inc for 16-byte slots
         return (o ^ (((f >> 1) & 15u) ^ ((0u - (f & 1u)) & 15u))) << amp_shift;
     };
     bool closed = true, skips = false;

@@ -112,18 +112,18 @@ struct Pass {
 };
 
 // What a pass costs, in bytes moved at the rate of a pass that is bound by its memory traffic.  A tile pass is: up to four
-// merged blocks hide behind the HBM time of the sweep, every further one adds 8.4 % of it (fp64; fp32 moves half the bytes per
-// amplitude under the same blocks: 16 % from the fourth on).  Fitted on the tile passes of six circuits under six cluster caps at
-// n = 30 (tools/pass_model_data.py; profiles/r04/pass_model_n30.csv, 591 passes with round 4's block phase):
-// ms = visited x (6.96 + 0.58 x max(0, blocks - 4)), rms error 0.53 ms (round 3's kernel: 6.93 + 0.77 per block); fp32 states
-// (pass_model_n30_f32.csv): 3.51 + 0.57 x max(0, blocks - 3), rms 0.24 ms.  The planning steps (engine: which schedule; shard
-// planner: which segmentation) rank by the sum of this — fewer sweeps are worth more than leaner ones, but not at any number of
-// blocks.
+// merged blocks hide behind the HBM time of the sweep, every further one adds 6.0 % of it (fp64; fp32 moves half the bytes per
+// amplitude under the same blocks: 8.9 % from the fourth on).  Fitted on the tile passes of seven circuits under twelve scheduler
+// settings at n = 30 with the kernel of the end of round 4 (tools/pass_model_data.py; profiles/r04/pass_model_n30_last_tree.csv, 1347 passes):
+// ms = visited x (7.16 + 0.43 x max(0, blocks - 4)), rms error 0.43 ms (before the lanes walked conflict-free bits: 0.49 per block on the
+// same settings; round 4's first fit 0.58, round 3's kernel 0.77); fp32 states (pass_model_n30_f32_last_tree.csv): 3.67 + 0.33 x
+// max(0, blocks - 3), rms 0.24 ms (0.57 per block before the fp32 swizzle).  The planning steps (engine: which schedule; shard planner:
+// which segmentation) rank by the sum of this — fewer sweeps are worth more than leaner ones, but not at any number of blocks.
 inline double pass_time_cost(const Pass &p, bool f32) {
     if (p.kclass != QSIM_K_TILE) return p.bytes;
     const int nb = (int)p.blocks.size() - p.geom.n_scale;
     const int over = f32 ? (nb > 3 ? nb - 3 : 0) : (nb > 4 ? nb - 4 : 0);
-    return p.bytes * p.visited * (1.0 + (f32 ? 0.163 : 0.084) * over);
+    return p.bytes * p.visited * (1.0 + (f32 ? 0.089 : 0.060) * over);
 }
 
 struct SchedConfig {
